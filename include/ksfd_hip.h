@@ -1,0 +1,175 @@
+/*
+ * ksfd_hip.h -- C ABI of libksfd_hip.so, the MI355X (gfx950) implementation of the hot path of
+ * leonavery/KSFD: RHS stencil, analytic Jacobian action, CFL velocity and the implicit
+ * (PETSc "TS ROSW ra34pw2"-equivalent) time step, for the periodic 4th-order finite-difference
+ * Keller-Segel system in 1, 2 or 3 dimensions.
+ *
+ * The reference has no FFI for this path: the seam is the Python object
+ * `implicitTS(derivs, t0, dt, tmax, maxsteps, rtol, atol)` (KSFD/ksfdts.py:500-561) whose
+ * TS.step() calls back into Derivatives.dfdt / Derivatives.Jacobian (KSFD/ksfdsym.py:902-940,
+ * 814-886).  Each entry point below names the reference code it stands in for.  The ctypes
+ * binding a maintainer would add is shown in INTEGRATION.md; ksfd_amd/lib.py is that binding.
+ *
+ * Conventions: every function returns 0 on success or a KSFD_E* code; ksfd_last_error() gives
+ * the message (mirrors the CHKERR -> RuntimeError convention of cython/ksfdMat/ksfdMat.pyx:17-20).
+ * One host thread per handle.  The handle owns all device memory, streams and events; callers
+ * own host buffers.  No callbacks into the host language except the optional halo transport.
+ */
+#ifndef KSFD_HIP_H
+#define KSFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSFD_MAX_LIG 6   /* ligand fields after the reference's fourier_series() expansion */
+
+enum {
+    KSFD_OK = 0,
+    KSFD_EINVAL = 1,      /* bad argument / unsupported configuration */
+    KSFD_EHIP = 2,        /* a HIP runtime call failed */
+    KSFD_ENOMEM = 3,
+    KSFD_ELINEAR = 4,     /* linear solve did not converge (the reference's SNES failure, ksfdts.py:135) */
+    KSFD_ENAN = 5,        /* non-finite error norm */
+    KSFD_EREJECT = 6,     /* step rejected more than max_reject times (PETSc TS_DIVERGED_STEP_REJECTED) */
+    KSFD_ECOMM = 7        /* halo / reduction transport failed */
+};
+
+/* Host-buffer layouts of an (F fields x local grid) state.  F = nlig + 1, field 0 = rho. */
+enum {
+    KSFD_LAYOUT_PETSC = 0, /* dof fastest: c + F*(i + nx*(j + ny*k))   KSFD/ksfdgrid.py:9-58 */
+    KSFD_LAYOUT_SOA = 1,   /* device order, x fastest: i + nx*(j + ny*(k + nz*c)) */
+    KSFD_LAYOUT_HDF5 = 2   /* (c,x,y[,z]) C order, last axis fastest  KSFD/ksfdtimeseries.py:497-505 */
+};
+
+/* Numeric problem description = what ps.values(t) and ps.Vgroups.ligands() give the reference's
+ * operators (KSFD/ksfdsoln.py:104-161, KSFD/ksfdligand.py:306-388, 527-547). */
+typedef struct ksfd_config {
+    int32_t dim;            /* 1, 2, 3 */
+    int32_t nlig;           /* <= KSFD_MAX_LIG */
+    int32_t ngroups;
+    int32_t cap_kind;       /* 0 tophat, 1 witch   (KSFD/ksfdsoln.py:150-157) */
+    int64_t n[3];           /* GLOBAL grid points per axis, unused axes = 1 */
+    double L[3];            /* box lengths; spacing = L/n, periodic (KSFD/ksfdgrid.py:138-149) */
+    double s2, rhomax, cushion, maxscale, rhomin, Umin;
+    const int32_t *lig_group;      /* [nlig] 0-based group of each ligand */
+    const double *lig_w, *lig_s, *lig_gamma, *lig_D;   /* [nlig] */
+    const double *grp_alpha, *grp_beta;                /* [ngroups] */
+} ksfd_config;
+
+/* Slab decomposition along the slowest spatial axis (y in 2-D, z in 3-D) -- the build's stand-in for
+ * the PETSc DMDA ghost exchange of width 2 (KSFD/ksfdgrid.py:388-411; globalToLocal at
+ * KSFD/ksfdsym.py:704,787,920,1203).  rank r owns slow-axis indices [r*n/size, (r+1)*n/size).
+ * transport: 0 none (size must be 1), 1 RCCL (ncclSend/ncclRecv + ncclAllReduce inside the library;
+ * nccl_id = the 128-byte ncclUniqueId broadcast by the launcher), 2 host callbacks (exchange /
+ * allreduce run by the caller, e.g. mpi4py or torch.distributed; buffers are HOST pointers). */
+typedef int (*ksfd_exchange_fn)(void *ctx, const double *send_lo, const double *send_hi,
+                                double *recv_lo, double *recv_hi, int64_t count);
+typedef int (*ksfd_allreduce_fn)(void *ctx, double *buf, int32_t count, int32_t op /*0 sum, 1 max*/);
+typedef struct ksfd_dist {
+    int32_t rank, size;
+    int32_t transport;
+    int32_t device;                /* HIP device ordinal for this rank */
+    const void *nccl_id;           /* transport 1 */
+    ksfd_exchange_fn exchange;     /* transport 2 */
+    ksfd_allreduce_fn allreduce;   /* transport 2 */
+    void *ctx;
+} ksfd_dist;
+
+/* Time-step controls = the PETSc options every shipped options file passes
+ * (options84:47-67: -ts_type rosw -ts_adapt_type basic -ts_adapt_clip 0.1,5 -ts_adapt_dt_min/max)
+ * plus the Krylov knobs that replace -ksp_type preonly -pc_type lu. */
+typedef struct ksfd_step_opts {
+    double rtol, atol;          /* TSSetTolerances (KSFD/ksfdts.py:136) */
+    int32_t adapt;              /* 1 = TSAdaptBasic, 0 = -ts_adapt_type none */
+    int32_t max_reject;         /* rejections tolerated inside one call (PETSc default 10); <0: single attempt */
+    double clip_lo, clip_hi;    /* 0.1, 5 */
+    double dt_min, dt_max;      /* 1e-20, 1e4 */
+    double safety, reject_safety; /* 0.9, 0.5 */
+    double ksp_rtol, ksp_atol;  /* GMRES: stop at ||r|| <= max(ksp_rtol*||b||, ksp_atol) */
+    int32_t ksp_restart, ksp_max_it;
+    int32_t pc_type;            /* 0 none (round 1) */
+    int32_t reserved;
+} ksfd_step_opts;
+
+typedef struct ksfd_step_stats {
+    int32_t accepted;           /* 1 if the state advanced */
+    int32_t rejections;
+    int32_t linear_its;         /* GMRES iterations over all stages and attempts */
+    int32_t rhs_evals, jvp_evals;
+    int32_t reserved;
+    double wrms;                /* error norm of the last attempt */
+    double h_used;              /* step actually taken (valid when accepted) */
+    double ksp_resid;           /* last relative residual */
+    double bytes;               /* algorithmic HBM bytes of all kernels launched by the call */
+} ksfd_step_stats;
+
+/* Per-kernel-class timing gathered with HIP events on the library's compute stream. */
+#define KSFD_NKCLASS 12
+typedef struct ksfd_profile {
+    double ms[KSFD_NKCLASS];       /* accumulated device time */
+    double bytes[KSFD_NKCLASS];    /* accumulated algorithmic bytes */
+    int64_t launches[KSFD_NKCLASS];
+} ksfd_profile;
+const char *ksfd_kernel_class_name(int32_t cls);
+
+typedef struct ksfd_handle ksfd_handle;
+
+/* -- lifetime.  dist == NULL: single GPU (device 0 or HIP_VISIBLE_DEVICES), in-kernel periodic wrap. */
+int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_handle **out);
+void ksfd_destroy(ksfd_handle *h);
+const char *ksfd_last_error(const ksfd_handle *h);          /* h may be NULL: error of a failed create */
+int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg);   /* time-dependent ps.values(t) */
+int ksfd_local_range(const ksfd_handle *h, int64_t *slow_begin, int64_t *slow_end); /* Grid._ranges on the slab axis */
+int64_t ksfd_local_size(const ksfd_handle *h);               /* F * local points: length of every host buffer */
+
+/* -- state (the TS solution Vec u; KSFD/ksfdts.py:141-152).  Host buffers hold the LOCAL slab. */
+int ksfd_set_state(ksfd_handle *h, const double *u_host, int32_t layout);
+int ksfd_get_state(ksfd_handle *h, double *u_host, int32_t layout);
+double *ksfd_device_state(ksfd_handle *h);      /* device pointer, SoA with ghost rows; plane stride below */
+int64_t ksfd_device_plane_stride(const ksfd_handle *h);
+int64_t ksfd_device_interior_offset(const ksfd_handle *h);
+
+/* -- sources(t) added by Derivatives.dfdt (KSFD/ksfdsym.py:930-936).  stage -1 sets all four stage
+ *    slots; stage 0..3 sets the field used at stage time t + ASum[stage]*h.  NULL clears. */
+int ksfd_set_source(ksfd_handle *h, int32_t stage, int32_t field, const double *src_host, int32_t layout);
+
+/* -- operators on host vectors (parity tests and host-driven integrators).
+ *    u_host == NULL: use the handle's state.  Inputs are clamped the way Derivatives.groom does
+ *    (KSFD/ksfdsym.py:888-900) on the fly; the stored state is not modified. */
+int ksfd_rhs(ksfd_handle *h, double t, const double *u_host, double *out_host, int32_t layout);   /* Derivatives.dfdt */
+int ksfd_jvp(ksfd_handle *h, const double *u_host, const double *v_host, double *out_host,
+             int32_t layout);                                    /* action of Derivatives.Jacobian(u) on v */
+int ksfd_velocity(ksfd_handle *h, const double *u_host, double *vel_host, int32_t layout); /* Derivatives.velocity: dim planes */
+int ksfd_velocity_max(ksfd_handle *h, double vmax[3]);           /* per-axis max|grad G| of the state; CFL_step, ksfdts.py:302-319 */
+
+/* -- outer-loop helpers of KSFDTS.solve (KSFD/ksfdts.py:202-284) acting on the device state */
+int ksfd_groom(ksfd_handle *h);                                  /* KSFDTS.groom :231-237 */
+int ksfd_count_worms(ksfd_handle *h, double *total);             /* sum(rho) over all ranks :239-246 */
+int ksfd_scale_rho(ksfd_handle *h, double factor);               /* conserve_worms :248-256 */
+int ksfd_mul_rho(ksfd_handle *h, const double *factor_host);     /* add_variance: rho *= exp(sd*N(0,1)) :268-284; local SoA plane */
+
+/* -- the implicit step that replaces petsc4py TS.step() (KSFD/ksfdts.py:211):
+ *    4-stage Rosenbrock-W RA34PW2 with frozen Jacobian J(t_n,u_n), shift 1/(gamma h), each stage
+ *    solved matrix-free by restarted GMRES on the device; TSAdaptBasic error control.
+ *    in: *t, *hstep (step to try).  out: *t advanced when accepted, *hstep = next proposed step. */
+void ksfd_default_step_opts(ksfd_step_opts *o);
+int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_step_opts *opts, ksfd_step_stats *stats);
+int ksfd_get_last_error_vector(ksfd_handle *h, double *err_host, int32_t layout); /* embedded-minus-main of last attempt */
+
+/* -- measurement */
+int ksfd_set_profiling(ksfd_handle *h, int32_t on);
+int ksfd_get_profile(ksfd_handle *h, ksfd_profile *p, int32_t reset);
+int ksfd_synchronize(ksfd_handle *h);
+/* raw kernel benchmark used by bench.py/profiles: run `reps` launches of one kernel class on the state,
+ * timed with HIP events on the compute stream; returns average ms per launch. */
+int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms, double *bytes_per_launch);
+int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSFD_HIP_H */

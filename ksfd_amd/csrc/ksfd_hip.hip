@@ -1,0 +1,967 @@
+// libksfd_hip.so -- host side: handle, C ABI (include/ksfd_hip.h), matrix-free GMRES and the
+// Rosenbrock-W step that stand in for petsc4py TS.step() in the reference (KSFD/ksfdts.py:211).
+// gfx950 only.  No CPU fallback: every entry point runs HIP kernels or fails.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ksfd_hip.h"
+#include "stencil.hip.h"
+#include "transport.h"
+
+// ------------------------------------------------------------------------------------------------
+// kernel classes for the profile
+enum { KC_RHS = 0, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE,
+       KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO };
+static const char *kc_names[KSFD_NKCLASS] = { "rhs", "jvp", "multidot", "gs_update", "lincomb", "basis_axpy",
+                                              "rosw_finish", "reduce", "gfield", "velocity", "misc", "halo" };
+extern "C" const char *ksfd_kernel_class_name(int32_t c) { return (c >= 0 && c < KSFD_NKCLASS) ? kc_names[c] : "?"; }
+
+static thread_local std::string g_create_error;
+
+struct EvPair { hipEvent_t a, b; int cls; };
+
+struct ksfd_handle {
+    ksfd_config cfg;
+    int32_t lig_group[KSFD_MAXL];
+    double lig_w[KSFD_MAXL], lig_s[KSFD_MAXL], lig_gamma[KSFD_MAXL], lig_D[KSFD_MAXL];
+    double grp_alpha[KSFD_MAXL], grp_beta[KSFD_MAXL];
+    KGeom G;
+    KPhys P;
+    KVec kv;
+    int rank = 0, size = 1, device = 0;
+    int64_t slow0 = 0;               // first owned global slow index
+    hipStream_t st = nullptr;
+    Transport *tr = nullptr;
+    std::string err;
+
+    // device vectors (each F*plane doubles)
+    int64_t vlen = 0;
+    double *u = nullptr, *usave = nullptr, *Z = nullptr, *bvec = nullptr, *Y = nullptr, *V = nullptr;
+    double *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *errv = nullptr;
+    double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes
+    double *flat = nullptr;                 // staging for host layouts: max(F,dim)*nloc
+    double *src[4][KSFD_MAXL + 1];          // dense source planes per stage (lazy)
+    double *part = nullptr;                 // block partials
+    double *dres = nullptr;                 // reduced results (device)
+    double *hres = nullptr;                 // pinned host mirror
+    int restart_alloc = 0;
+    int nblk_vec = 0;                       // grid.x of the BLAS-1 kernels
+    bool have_err = false;
+
+    // tuning
+    int use_fused = 1;
+    int yseg = 32;
+
+    // profile
+    bool profiling = false;
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> pool;
+    ksfd_profile prof;
+    double bytes_acc = 0.0;
+
+    // ROSW tableau (PETSc transformed form)
+    double At[4][4], Ginv[4][4], bt[4], b2t[4], asum[4];
+};
+
+#define GAMMA_RA 4.3586652150845900e-01
+
+static int fail(ksfd_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIPCHK(h, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return fail(h, KSFD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- profiling helpers -------------------------------------------------------------------------
+static hipEvent_t ev_get(ksfd_handle *h)
+{
+    if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct Scope {
+    ksfd_handle *h; EvPair p; bool on;
+    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling)
+    {
+        h->bytes_acc += bytes;
+        h->prof.bytes[cls] += bytes;
+        h->prof.launches[cls] += 1;
+        if (on) { p.a = ev_get(h); p.b = ev_get(h); p.cls = cls; hipEventRecord(p.a, h->st); }
+    }
+    ~Scope() { if (on) { hipEventRecord(p.b, h->st); h->pending.push_back(p); } }
+};
+static void prof_resolve(ksfd_handle *h)
+{
+    if (h->pending.empty()) return;
+    hipStreamSynchronize(h->st);
+    for (auto &p : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->prof.ms[p.cls] += ms;
+        h->pool.push_back(p.a);
+        h->pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+// ---- small utilities ---------------------------------------------------------------------------
+static inline dim3 vgrid(const ksfd_handle *h) { return dim3(h->nblk_vec, h->G.F); }
+static inline double vbytes(const ksfd_handle *h, double nvec) { return nvec * 8.0 * (double)h->G.F * (double)h->G.nloc; }
+
+static void build_tableau(ksfd_handle *h)
+{
+    static const double A[4][4] = { { 0, 0, 0, 0 }, { 8.7173304301691801e-01, 0, 0, 0 },
+                                    { 8.4457060015369423e-01, -1.1299064236484185e-01, 0, 0 }, { 0, 0, 1., 0 } };
+    static const double Gm[4][4] = { { GAMMA_RA, 0, 0, 0 }, { -8.7173304301691801e-01, GAMMA_RA, 0, 0 },
+                                     { -9.0338057013044082e-01, 5.4180672388095326e-02, GAMMA_RA, 0 },
+                                     { 2.4212380706095346e-01, -1.2232505839045147e+00, 5.4526025533510214e-01, GAMMA_RA } };
+    static const double b[4] = { 2.4212380706095346e-01, -1.2232505839045147e+00, 1.5452602553351020e+00, GAMMA_RA };
+    static const double b2[4] = { 3.7810903145819369e-01, -9.6042292212423178e-02, 0.5, 2.1793326075422950e-01 };
+    memset(h->Ginv, 0, sizeof h->Ginv);
+    for (int col = 0; col < 4; col++)
+        for (int i = col; i < 4; i++) {
+            double s = (i == col) ? 1.0 : 0.0;
+            for (int k = col; k < i; k++) s -= Gm[i][k] * h->Ginv[k][col];
+            h->Ginv[i][col] = s / Gm[i][i];
+        }
+    for (int i = 0; i < 4; i++) {
+        h->asum[i] = 0.0;
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += A[i][k] * h->Ginv[k][j];
+            h->At[i][j] = s;
+            h->asum[i] += A[i][j];
+        }
+    }
+    for (int j = 0; j < 4; j++) {
+        double s = 0.0, s2 = 0.0;
+        for (int k = 0; k < 4; k++) { s += b[k] * h->Ginv[k][j]; s2 += b2[k] * h->Ginv[k][j]; }
+        h->bt[j] = s;
+        h->b2t[j] = s2;
+    }
+}
+
+static int fill_phys(ksfd_handle *h, const ksfd_config *c)
+{
+    if (c->nlig < 1 || c->nlig > KSFD_MAXL || c->ngroups < 1 || c->ngroups > KSFD_MAXL)
+        return fail(h, KSFD_EINVAL, "nlig=%d ngroups=%d outside 1..%d", c->nlig, c->ngroups, KSFD_MAXL);
+    KPhys &P = h->P;
+    memset(&P, 0, sizeof P);
+    P.nlig = c->nlig; P.ngroups = c->ngroups; P.cap_kind = c->cap_kind;
+    for (int a = 0; a < 3; a++) {
+        double sp = c->L[a] / (double)c->n[a];
+        P.inv_h[a] = 1.0 / sp;
+        P.inv_h2[a] = 1.0 / (sp * sp);
+    }
+    P.s2 = c->s2; P.rhomax = c->rhomax; P.inv_cushion = 1.0 / c->cushion; P.ms = c->maxscale * c->s2;
+    P.rhomin = c->rhomin; P.Umin = c->Umin; P.inv_rhomax = 1.0 / c->rhomax;
+    for (int l = 0; l < c->nlig; l++) {
+        if (c->lig_group[l] < 0 || c->lig_group[l] >= c->ngroups) return fail(h, KSFD_EINVAL, "lig_group[%d] out of range", l);
+        P.lig_group[l] = h->lig_group[l] = c->lig_group[l];
+        P.lig_w[l] = h->lig_w[l] = c->lig_w[l];
+        P.lig_s[l] = h->lig_s[l] = c->lig_s[l];
+        P.lig_gamma[l] = h->lig_gamma[l] = c->lig_gamma[l];
+        P.lig_D[l] = h->lig_D[l] = c->lig_D[l];
+    }
+    for (int l = c->nlig; l < KSFD_MAXL; l++) P.lig_group[l] = -1;
+    for (int q = 0; q < c->ngroups; q++) {
+        P.grp_alpha[q] = h->grp_alpha[q] = c->grp_alpha[q];
+        P.grp_beta[q] = h->grp_beta[q] = c->grp_beta[q];
+    }
+    return KSFD_OK;
+}
+
+static int alloc_d(ksfd_handle *h, double **p, int64_t n)
+{
+    if (hipMalloc((void **)p, sizeof(double) * (size_t)n) != hipSuccess) return fail(h, KSFD_ENOMEM, "hipMalloc of %lld doubles failed", (long long)n);
+    return KSFD_OK;
+}
+
+static bool fused_ok(const ksfd_handle *h)
+{
+    return h->use_fused && h->G.dim == 2 && (h->G.nx % 2 == 0) && h->G.nx >= 4 && h->P.nlig <= 4;
+}
+
+// ---- halo exchange (DMDA globalToLocal stand-in, KSFD/ksfdsym.py:919-920) -----------------------
+static int halo(ksfd_handle *h, double *vec)
+{
+    if (h->size == 1) return KSFD_OK;
+    Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * h->G.F * (double)h->G.inner * 2.0);
+    int rc = h->tr->exchange(vec, h->G.F, h->G.plane, h->G.inner, h->G.sloc, h->G.ng, h->st);
+    if (rc) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    return KSFD_OK;
+}
+
+// ---- reductions to the host ------------------------------------------------------------------
+// part holds `rows` rows of `nblk` partials; result lands in h->hres[0..rows)
+static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
+{
+    {
+        Scope sc(h, KC_REDUCE, 8.0 * rows * (double)nblk);
+        hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres);
+    }
+    if (h->size > 1) {
+        int rc = h->tr->allreduce(h->dres, rows, op, h->st);
+        if (rc) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
+        if (h->tr->result_on_host()) { memcpy(h->hres, h->tr->host_result(), sizeof(double) * rows); return KSFD_OK; }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, sizeof(double) * rows, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+// ---- kernel wrappers ----------------------------------------------------------------------------
+#define NL_DISPATCH(nl, CALL)                                                                      \
+    switch (nl) {                                                                                  \
+    case 1: { constexpr int NL = 1; CALL; } break;                                                 \
+    case 2: { constexpr int NL = 2; CALL; } break;                                                 \
+    case 3: { constexpr int NL = 3; CALL; } break;                                                 \
+    case 4: { constexpr int NL = 4; CALL; } break;                                                 \
+    case 5: { constexpr int NL = 5; CALL; } break;                                                 \
+    default: { constexpr int NL = 6; CALL; } break;                                                \
+    }
+
+static KStrips make_strips(const ksfd_handle *h)
+{
+    KStrips S;
+    S.nstrips = (int)((h->G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+    S.yseg = h->yseg;
+    S.nseg = (int)((h->G.sloc + S.yseg - 1) / S.yseg);
+    long long waves = (long long)S.nstrips * S.nseg;
+    long long nb = (waves + 3) / 4;
+    nb = (nb + 7) / 8 * 8;
+    S.nblocks = (int)nb;
+    return S;
+}
+
+static KSrc src_of(const ksfd_handle *h, int stage)
+{
+    KSrc s;
+    for (int c = 0; c <= KSFD_MAXL; c++) s.p[c] = (stage >= 0 && c < h->G.F) ? h->src[stage][c] : nullptr;
+    return s;
+}
+
+// out = f(u) (+sources of `stage`); u must have valid ghosts when size>1
+static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out)
+{
+    const KGeom &G = h->G;
+    KSrc S = src_of(h, stage);
+    if (fused_ok(h)) {
+        KStrips K = make_strips(h);
+        Scope sc(h, KC_RHS, vbytes(h, 2));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (G.F + 1) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, (const double *)nullptr, h->Gb, (double *)nullptr));
+        }
+        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_RHS, vbytes(h, 2) + 8.0 * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_rhs_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->Gb, S, out));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// out = J(u) v (mode 0) or shift*v - J(u) v (mode 1); u and v need valid ghosts when size>1
+static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, double shift, double *out)
+{
+    const KGeom &G = h->G;
+    if (fused_ok(h)) {
+        KStrips K = make_strips(h);
+        Scope sc(h, KC_JVP, vbytes(h, 3));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, v, mode, shift, out));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 * G.F + 2) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, true>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb));
+        }
+        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_JVP, vbytes(h, 3) + 16.0 * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb, mode, shift, out));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const double *a, double *out)
+{
+    KLin L;
+    for (int t = 0; t < 6; t++) { L.x[t] = t < nt ? x[t] : nullptr; L.a[t] = t < nt ? a[t] : 0.0; }
+    Scope sc(h, KC_LINCOMB, vbytes(h, nt + 1));
+    switch (nt) {
+    case 1: hipLaunchKernelGGL((k_lincomb<1>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    case 2: hipLaunchKernelGGL((k_lincomb<2>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    case 3: hipLaunchKernelGGL((k_lincomb<3>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    case 4: hipLaunchKernelGGL((k_lincomb<4>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    case 5: hipLaunchKernelGGL((k_lincomb<5>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    default: hipLaunchKernelGGL((k_lincomb<6>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// d[0..k) = <w,V_i>, d[k] = <w,w>  -> h->hres
+static int op_multidot(ksfd_handle *h, const double *w, const double *V, int k)
+{
+    const int nb = h->nblk_vec;
+    {
+        Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
+        if (k <= 4) hipLaunchKernelGGL((k_multidot<4>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
+        else if (k <= 8) hipLaunchKernelGGL((k_multidot<8>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
+        else if (k <= 16) hipLaunchKernelGGL((k_multidot<16>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
+        else hipLaunchKernelGGL((k_multidot<32>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
+    }
+    HIPCHK(h, hipGetLastError());
+    return reduce_rows(h, k + 1, nb, 0);
+}
+
+static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const double *coef, double scale)
+{
+    KCoef C;
+    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
+    Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
+    if (k <= 4) hipLaunchKernelGGL((k_gs_update<4>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
+    else if (k <= 8) hipLaunchKernelGGL((k_gs_update<8>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
+    else if (k <= 16) hipLaunchKernelGGL((k_gs_update<16>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
+    else hipLaunchKernelGGL((k_gs_update<32>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta)
+{
+    KCoef C;
+    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
+    Scope sc(h, KC_BASISAXPY, vbytes(h, k + 1 + (beta != 0.0)));
+    if (k <= 4) hipLaunchKernelGGL((k_basis_axpy<4>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
+    else if (k <= 8) hipLaunchKernelGGL((k_basis_axpy<8>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
+    else if (k <= 16) hipLaunchKernelGGL((k_basis_axpy<16>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
+    else hipLaunchKernelGGL((k_basis_axpy<32>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int op_copy(ksfd_handle *h, double *dst, const double *src)
+{
+    Scope sc(h, KC_MISC, vbytes(h, 2));
+    HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
+    return KSFD_OK;
+}
+
+// ---- host <-> device vectors -------------------------------------------------------------------
+static int upload(ksfd_handle *h, const double *host, int layout, double *dev)
+{
+    const KGeom &G = h->G;
+    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
+    HIPCHK(h, hipMemcpyAsync(h->flat, host, sizeof(double) * (size_t)G.F * G.nloc, hipMemcpyHostToDevice, h->st));
+    Scope sc(h, KC_MISC, vbytes(h, 2));
+    hipLaunchKernelGGL(k_from_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, h->flat, dev, G.plane,
+                       (long long)G.ng * G.inner);
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+static int download(ksfd_handle *h, const double *dev, int layout, double *host)
+{
+    const KGeom &G = h->G;
+    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
+    {
+        Scope sc(h, KC_MISC, vbytes(h, 2));
+        hipLaunchKernelGGL(k_to_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, dev, G.plane,
+                           (long long)G.ng * G.inner, h->flat);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(host, h->flat, sizeof(double) * (size_t)G.F * G.nloc, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *ksfd_last_error(const ksfd_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void ksfd_destroy(ksfd_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->st) hipStreamSynchronize(h->st);
+    double *bufs[] = { h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
+    for (double *b : bufs) if (b) hipFree(b);
+    for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
+    if (h->hres) hipHostFree(h->hres);
+    for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : h->pool) hipEventDestroy(e);
+    delete h->tr;
+    if (h->st) hipStreamDestroy(h->st);
+    delete h;
+}
+
+extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, KSFD_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->dim < 1 || cfg->dim > 3) return fail(nullptr, KSFD_EINVAL, "dim must be 1, 2 or 3");
+    for (int a = 0; a < cfg->dim; a++)
+        if (cfg->n[a] < 5) return fail(nullptr, KSFD_EINVAL, "n[%d]=%lld < 5: the width-2 periodic star needs >= 5 points", a, (long long)cfg->n[a]);
+    ksfd_handle *h = new ksfd_handle();
+    memset(h->src, 0, sizeof h->src);
+    memset(&h->prof, 0, sizeof h->prof);
+    h->cfg = *cfg;
+    int rc = fill_phys(h, cfg);
+    if (rc) { g_create_error = h->err; delete h; return rc; }
+    h->rank = dist ? dist->rank : 0;
+    h->size = dist ? dist->size : 1;
+    h->device = dist ? dist->device : 0;
+    if (h->size < 1 || h->rank < 0 || h->rank >= h->size) { delete h; return fail(nullptr, KSFD_EINVAL, "bad rank/size"); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete h; return fail(nullptr, KSFD_EHIP, "no HIP device available (libksfd_hip has no CPU path)"); }
+    if (h->device < 0 || h->device >= ndev) { delete h; return fail(nullptr, KSFD_EINVAL, "device %d of %d", h->device, ndev); }
+#define CFAIL(code, ...) do { int rc_ = fail(nullptr, code, __VA_ARGS__); ksfd_destroy(h); return rc_; } while (0)
+    if (hipSetDevice(h->device) != hipSuccess) CFAIL(KSFD_EHIP, "hipSetDevice(%d) failed", h->device);
+    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) CFAIL(KSFD_EHIP, "hipStreamCreate failed");
+
+    KGeom &G = h->G;
+    G.dim = cfg->dim; G.F = cfg->nlig + 1;
+    const int slow = cfg->dim - 1;
+    int64_t nglob = cfg->n[slow];
+    if (h->size > 1 && (nglob % h->size != 0 || nglob / h->size < 4))
+        CFAIL(KSFD_EINVAL, "slab axis extent %lld must be divisible by %d ranks with >= 4 units each", (long long)nglob, h->size);
+    int64_t sloc = nglob / h->size;
+    h->slow0 = sloc * h->rank;
+    G.ng = h->size > 1 ? 2 : 0;
+    G.wrap_slow = h->size == 1;
+    G.nx = cfg->n[0]; G.ny = cfg->dim >= 2 ? cfg->n[1] : 1; G.nz = cfg->dim >= 3 ? cfg->n[2] : 1;
+    if (slow == 0) G.nx = sloc; else if (slow == 1) G.ny = sloc; else G.nz = sloc;
+    G.inner = slow == 0 ? 1 : (slow == 1 ? G.nx : G.nx * G.ny);
+    G.sloc = sloc;
+    G.plane = (sloc + 2 * G.ng) * G.inner;
+    G.nloc = sloc * G.inner;
+    h->kv.plane = G.plane; h->kv.off = (long long)G.ng * G.inner; h->kv.nloc = G.nloc; h->kv.nf = G.F;
+    h->vlen = (int64_t)G.F * G.plane;
+    h->nblk_vec = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 1024);
+    build_tableau(h);
+
+    h->restart_alloc = 30;
+    double **vecs[] = { &h->u, &h->usave, &h->Z, &h->bvec, &h->t1, &h->t2, &h->t3, &h->errv };
+    for (double **v : vecs) {
+        if (alloc_d(h, v, h->vlen)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
+        hipMemsetAsync(*v, 0, sizeof(double) * (size_t)h->vlen, h->st);
+    }
+    if (alloc_d(h, &h->Y, 4 * h->vlen) || alloc_d(h, &h->V, (int64_t)(h->restart_alloc + 1) * h->vlen) ||
+        alloc_d(h, &h->Gb, G.plane) || alloc_d(h, &h->dGb, G.plane) ||
+        alloc_d(h, &h->flat, (int64_t)std::max(G.F, 3) * G.nloc) ||
+        alloc_d(h, &h->part, (int64_t)(KSFD_MAXDOT + 2) * 4096) || alloc_d(h, &h->dres, 64))
+        CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
+    hipMemsetAsync(h->Y, 0, sizeof(double) * (size_t)(4 * h->vlen), h->st);
+    hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)((h->restart_alloc + 1) * h->vlen), h->st);
+    if (hipHostMalloc((void **)&h->hres, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
+
+    if (h->size > 1) {
+        std::string terr;
+        h->tr = make_transport(dist, G.F, G.inner, terr);
+        if (!h->tr) CFAIL(KSFD_ECOMM, "transport %d: %s", dist->transport, terr.c_str());
+    }
+    if (hipStreamSynchronize(h->st) != hipSuccess) CFAIL(KSFD_EHIP, "stream sync failed in create");
+#undef CFAIL
+    *out = h;
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg)
+{
+    if (!h || !cfg) return KSFD_EINVAL;
+    if (cfg->dim != h->cfg.dim || cfg->nlig != h->cfg.nlig) return fail(h, KSFD_EINVAL, "update_params cannot change dim/nlig");
+    for (int a = 0; a < 3; a++) if (cfg->n[a] != h->cfg.n[a]) return fail(h, KSFD_EINVAL, "update_params cannot change the grid");
+    h->cfg = *cfg;
+    return fill_phys(h, cfg);
+}
+
+extern "C" int ksfd_local_range(const ksfd_handle *h, int64_t *b, int64_t *e)
+{
+    if (!h) return KSFD_EINVAL;
+    if (b) *b = h->slow0;
+    if (e) *e = h->slow0 + h->G.sloc;
+    return KSFD_OK;
+}
+extern "C" int64_t ksfd_local_size(const ksfd_handle *h) { return h ? (int64_t)h->G.F * h->G.nloc : 0; }
+extern "C" double *ksfd_device_state(ksfd_handle *h) { return h ? h->u : nullptr; }
+extern "C" int64_t ksfd_device_plane_stride(const ksfd_handle *h) { return h ? h->G.plane : 0; }
+extern "C" int64_t ksfd_device_interior_offset(const ksfd_handle *h) { return h ? (int64_t)h->G.ng * h->G.inner : 0; }
+
+extern "C" int ksfd_set_state(ksfd_handle *h, const double *u, int32_t layout)
+{
+    if (!h || !u) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    int rc = upload(h, u, layout, h->u);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+extern "C" int ksfd_get_state(ksfd_handle *h, double *u, int32_t layout)
+{
+    if (!h || !u) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    return download(h, h->u, layout, u);
+}
+
+extern "C" int ksfd_set_source(ksfd_handle *h, int32_t stage, int32_t field, const double *srch, int32_t layout)
+{
+    if (!h || field < 0 || field >= h->G.F || stage < -1 || stage > 3) return h ? fail(h, KSFD_EINVAL, "bad stage/field") : KSFD_EINVAL;
+    if (layout != KSFD_LAYOUT_SOA) return fail(h, KSFD_EINVAL, "sources are single dense planes: pass layout SOA");
+    hipSetDevice(h->device);
+    for (int s = 0; s < 4; s++) {
+        if (stage != -1 && s != stage) continue;
+        if (!srch) {
+            if (h->src[s][field]) { HIPCHK(h, hipStreamSynchronize(h->st)); hipFree(h->src[s][field]); h->src[s][field] = nullptr; }
+            continue;
+        }
+        if (!h->src[s][field] && alloc_d(h, &h->src[s][field], h->G.nloc)) return KSFD_ENOMEM;
+        HIPCHK(h, hipMemcpyAsync(h->src[s][field], srch, sizeof(double) * (size_t)h->G.nloc, hipMemcpyHostToDevice, h->st));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_rhs(ksfd_handle *h, double t, const double *uh, double *outh, int32_t layout)
+{
+    (void)t;   // sources(t) are uploaded by the caller (ksfd_set_source); constants via ksfd_update_params
+    if (!h || !outh) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    int rc;
+    double *uin = h->u;
+    if (uh) { if ((rc = upload(h, uh, layout, h->t1))) return rc; uin = h->t1; }
+    if ((rc = halo(h, uin))) return rc;
+    if ((rc = op_rhs(h, uin, 0, h->t3))) return rc;
+    return download(h, h->t3, layout, outh);
+}
+
+extern "C" int ksfd_jvp(ksfd_handle *h, const double *uh, const double *vh, double *outh, int32_t layout)
+{
+    if (!h || !vh || !outh) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    int rc;
+    double *uin = h->u;
+    if (uh) { if ((rc = upload(h, uh, layout, h->t1))) return rc; uin = h->t1; }
+    if ((rc = upload(h, vh, layout, h->t2))) return rc;
+    if ((rc = halo(h, uin)) || (rc = halo(h, h->t2))) return rc;
+    if ((rc = op_jvp(h, uin, h->t2, 0, 0.0, h->t3))) return rc;
+    return download(h, h->t3, layout, outh);
+}
+
+static int velocity_common(ksfd_handle *h, const double *uin, double *vel_dev, double vmax[3])
+{
+    const KGeom &G = h->G;
+    int rc;
+    if ((rc = halo(h, (double *)uin))) return rc;
+    int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    {
+        Scope sc(h, KC_GFIELD, 8.0 * (G.F + 1) * (double)G.plane);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, uin, (const double *)nullptr, h->Gb, (double *)nullptr));
+    }
+    int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 1024);
+    {
+        Scope sc(h, KC_VELOCITY, 8.0 * (double)G.nloc * (1 + (vel_dev ? G.dim : 0)));
+        hipLaunchKernelGGL(k_velocity, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, h->Gb, vel_dev, vmax ? h->part : (double *)nullptr);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (vmax) {
+        if ((rc = reduce_rows(h, 3, nb, 1))) return rc;
+        for (int a = 0; a < 3; a++) vmax[a] = a < G.dim ? h->hres[a] : 0.0;
+    }
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_velocity(ksfd_handle *h, const double *uh, double *velh, int32_t layout)
+{
+    if (!h || !velh) return KSFD_EINVAL;
+    if (layout != KSFD_LAYOUT_SOA) return fail(h, KSFD_EINVAL, "velocity output is dim dense SoA planes: pass layout SOA for it");
+    hipSetDevice(h->device);
+    int rc;
+    double *uin = h->u;
+    if (uh) { if ((rc = upload(h, uh, layout, h->t1))) return rc; uin = h->t1; }
+    if ((rc = velocity_common(h, uin, h->flat, nullptr))) return rc;
+    HIPCHK(h, hipMemcpyAsync(velh, h->flat, sizeof(double) * (size_t)h->G.dim * h->G.nloc, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_velocity_max(ksfd_handle *h, double vmax[3])
+{
+    if (!h || !vmax) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    return velocity_common(h, h->u, nullptr, vmax);
+}
+
+extern "C" int ksfd_groom(ksfd_handle *h)
+{
+    if (!h) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    Scope sc(h, KC_MISC, vbytes(h, 2));
+    hipLaunchKernelGGL(k_groom, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, h->P.rhomin, h->P.Umin);
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_count_worms(ksfd_handle *h, double *total)
+{
+    if (!h || !total) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    {
+        Scope sc(h, KC_MISC, 8.0 * (double)h->G.nloc);
+        hipLaunchKernelGGL(k_sum_rho, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, h->part);
+    }
+    HIPCHK(h, hipGetLastError());
+    int rc = reduce_rows(h, 1, h->nblk_vec, 0);
+    if (rc) return rc;
+    *total = h->hres[0];
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_scale_rho(ksfd_handle *h, double factor)
+{
+    if (!h) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    Scope sc(h, KC_MISC, 16.0 * (double)h->G.nloc);
+    hipLaunchKernelGGL(k_mul_rho, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, (const double *)nullptr, factor);
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
+{
+    if (!h || !fh) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipMemcpyAsync(h->flat, fh, sizeof(double) * (size_t)h->G.nloc, hipMemcpyHostToDevice, h->st));
+    Scope sc(h, KC_MISC, 24.0 * (double)h->G.nloc);
+    hipLaunchKernelGGL(k_mul_rho, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, (const double *)h->flat, 1.0);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// matrix-free GMRES(m) for (shift I - J(u)) x = b, x0 = 0  -- replaces -ksp_type preonly -pc_type lu
+// (options84:58-60).  Classical Gram-Schmidt with one fused multi-dot per pass; a second pass
+// (DGKS-style refinement) only when the Pythagorean norm estimate has lost > 6 digits.
+// ------------------------------------------------------------------------------------------------
+struct LinStats { int its; double rel; };
+
+static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
+                 const ksfd_step_opts *o, LinStats *ls)
+{
+    const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
+    const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
+    const int64_t vs = h->vlen;
+    double *V = h->V;
+    int rc;
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2);
+    if ((rc = op_multidot(h, b, V, 0))) return rc;
+    const double bn = sqrt(h->hres[0]);
+    ls->its = 0; ls->rel = 0.0;
+    if (!(bn > 0.0)) {
+        if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
+        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
+        return KSFD_OK;
+    }
+    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
+    double beta = bn, rn = bn;
+    int total = 0;
+    bool first = true;
+    while (true) {
+        // V0 = r / beta
+        if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
+        else {
+            if ((rc = halo(h, x)) || (rc = op_jvp(h, ustate, x, 1, shift, V))) return rc;     // V0 = A x
+            const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
+            if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;                                  // r = b - A x
+            if ((rc = op_multidot(h, V, V, 0))) return rc;
+            beta = sqrt(h->hres[0]);
+            rn = beta;
+            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: residual is not finite");
+            if (beta <= tol) break;
+            const double *x1[1] = { V }; double a1[1] = { 1.0 / beta };
+            if ((rc = op_lincomb(h, 1, x1, a1, V))) return rc;
+        }
+        std::fill(g.begin(), g.end(), 0.0);
+        g[0] = beta;
+        int j = 0;
+        bool done = false;
+        for (; j < m && total < maxit; j++) {
+            double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
+            if ((rc = halo(h, vj)) || (rc = op_jvp(h, ustate, vj, 1, shift, w))) return rc;
+            const int k = j + 1;
+            if ((rc = op_multidot(h, w, V, k))) return rc;
+            for (int i = 0; i < k; i++) hcol[i] = h->hres[i];
+            double ww = h->hres[k], s2 = 0.0;
+            for (int i = 0; i < k; i++) s2 += hcol[i] * hcol[i];
+            double hn2 = ww - s2;
+            if (!(ww == ww)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+            if (hn2 < 1e-6 * ww) {
+                // refinement pass: subtract, re-project, accumulate
+                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
+                if ((rc = op_multidot(h, w, V, k))) return rc;
+                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; }
+                ww = h->hres[k];
+                s2 = 0.0;
+                for (int i = 0; i < k; i++) s2 += d[i] * d[i];
+                hn2 = ww - s2;
+                if (hn2 < 0.0) hn2 = 0.0;
+                const double hn = sqrt(hn2);
+                if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
+                hcol[k] = hn;
+            } else {
+                const double hn = sqrt(hn2);
+                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0 / hn))) return rc;
+                hcol[k] = hn;
+            }
+            double *Hc = &H[(size_t)(m + 1) * j];
+            for (int i = 0; i <= k; i++) Hc[i] = hcol[i];
+            for (int i = 0; i < j; i++) { double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1]; Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1]; Hc[i] = t; }
+            const double den = hypot(Hc[j], Hc[j + 1]);
+            cs[j] = den > 0.0 ? Hc[j] / den : 1.0;
+            sn[j] = den > 0.0 ? Hc[j + 1] / den : 0.0;
+            Hc[j] = den; Hc[j + 1] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            total++;
+            rn = fabs(g[j + 1]);
+            if (rn <= tol || hcol[k] == 0.0) { j++; done = true; break; }
+        }
+        for (int i = j - 1; i >= 0; i--) {
+            double s = g[i];
+            for (int q = i + 1; q < j; q++) s -= H[(size_t)(m + 1) * q + i] * y[q];
+            y[i] = s / H[(size_t)(m + 1) * i + i];
+        }
+        if ((rc = op_basis_axpy(h, x, V, j, y.data(), first ? 0.0 : 1.0))) return rc;
+        first = false;
+        if (done || total >= maxit) break;
+    }
+    ls->its = total;
+    ls->rel = rn / bn;
+    if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" void ksfd_default_step_opts(ksfd_step_opts *o)
+{
+    memset(o, 0, sizeof *o);
+    o->rtol = 1e-5; o->atol = 1e-5;           // KSFD/ksfdts.py:66-67 defaults
+    o->adapt = 1; o->max_reject = 10;
+    o->clip_lo = 0.1; o->clip_hi = 5.0;       // -ts_adapt_clip 0.1,5
+    o->dt_min = 1e-20; o->dt_max = 1e4;       // -ts_adapt_dt_min/-ts_adapt_dt_max
+    o->safety = 0.9; o->reject_safety = 0.5;  // PETSc TSAdaptBasic defaults
+    o->ksp_rtol = 1e-8; o->ksp_atol = 1e-50;
+    o->ksp_restart = 30; o->ksp_max_it = 2000;
+    o->pc_type = 0;
+}
+
+// One TSStep_RosW attempt loop (PETSc rosw.c restated; tableau/derivation in oracle/ksfd_oracle.c).
+extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_step_opts *opts, ksfd_step_stats *stats)
+{
+    if (!h || !t || !hstep || !opts) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    ksfd_step_stats st;
+    memset(&st, 0, sizeof st);
+    const double bytes0 = h->bytes_acc;
+    const int64_t rhs0 = h->prof.launches[KC_RHS], jvp0 = h->prof.launches[KC_JVP];
+    int rc = KSFD_OK;
+    const int64_t vs = h->vlen;
+    double hh = *hstep;
+    bool prev_accept = true;
+    int rejects = 0;
+    const int max_rej = opts->max_reject;
+    // KSFDTS.solve grooms the global vector before every TS.step (KSFD/ksfdts.py:210)
+    if ((rc = ksfd_groom(h))) goto out;
+    if ((rc = op_copy(h, h->usave, h->u))) goto out;
+    if ((rc = halo(h, h->u))) goto out;
+    while (true) {
+        const double shift = 1.0 / (GAMMA_RA * hh);
+        for (int i = 0; i < 4 && !rc; i++) {
+            const double *zin = h->u;
+            if (i > 0) {
+                const double *xs[5]; double a[5]; int nt = 0;
+                xs[nt] = h->u; a[nt++] = 1.0;
+                for (int j = 0; j < i; j++) if (h->At[i][j] != 0.0) { xs[nt] = h->Y + (int64_t)j * vs; a[nt++] = h->At[i][j]; }
+                if (nt > 1) {
+                    if ((rc = op_lincomb(h, nt, xs, a, h->Z))) break;
+                    if ((rc = halo(h, h->Z))) break;
+                    zin = h->Z;
+                }
+            }
+            if ((rc = op_rhs(h, zin, i, h->bvec))) break;
+            if (i > 0) {
+                const double *xs[5]; double a[5]; int nt = 0;
+                xs[nt] = h->bvec; a[nt++] = 1.0;
+                for (int j = 0; j < i; j++) if (h->Ginv[i][j] != 0.0) { xs[nt] = h->Y + (int64_t)j * vs; a[nt++] = -h->Ginv[i][j] / hh; }
+                if (nt > 1 && (rc = op_lincomb(h, nt, xs, a, h->bvec))) break;
+            }
+            LinStats ls;
+            rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls);
+            st.linear_its += ls.its;
+            st.ksp_resid = ls.rel;
+        }
+        if (rc) { op_copy(h, h->u, h->usave); hipStreamSynchronize(h->st); goto out; }
+        // completion + embedded error norm
+        {
+            Scope sc(h, KC_FINISH, vbytes(h, 7));
+            hipLaunchKernelGGL(k_rosw_finish, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, h->Y, vs,
+                               h->bt[0], h->bt[1], h->bt[2], h->bt[3], h->b2t[0] - h->bt[0], h->b2t[1] - h->bt[1],
+                               h->b2t[2] - h->bt[2], h->b2t[3] - h->bt[3], opts->atol, opts->rtol, h->errv, h->part);
+        }
+        h->have_err = true;
+        if ((rc = reduce_rows(h, 1, h->nblk_vec, 0))) goto out;
+        {
+            double ntot = (double)h->G.F * (double)h->cfg.n[0] * (double)h->cfg.n[1] * (double)h->cfg.n[2];
+            st.wrms = sqrt(h->hres[0] / ntot);
+        }
+        if (!(st.wrms == st.wrms) || isinf(st.wrms)) {
+            op_copy(h, h->u, h->usave); hipStreamSynchronize(h->st);
+            rc = fail(h, KSFD_ENAN, "non-finite error norm at t=%g h=%g", *t, hh);
+            goto out;
+        }
+        bool accept = true;
+        double hnext = hh;
+        if (opts->adapt) {
+            // TSAdaptChoose_Basic
+            double safety = opts->safety;
+            if (st.wrms > 1.0) {
+                if (!prev_accept) safety *= opts->reject_safety;
+                accept = hh < (1.0 + 1.4901161193847656e-08) * opts->dt_min;   // at minimum step: accept anyway
+            }
+            double hfac = st.wrms > 0.0 ? safety * pow(st.wrms, -1.0 / 3.0) : INFINITY;
+            hfac = std::min(std::max(hfac, opts->clip_lo), opts->clip_hi);
+            hnext = std::min(std::max(hh * hfac, opts->dt_min), opts->dt_max);
+        }
+        prev_accept = accept;
+        if (accept) {
+            st.accepted = 1; st.h_used = hh;
+            *t += hh;
+            *hstep = hnext;
+            break;
+        }
+        rejects++;
+        st.rejections = rejects;
+        if ((rc = op_copy(h, h->u, h->usave))) goto out;
+        hh = hnext;
+        *hstep = hnext;
+        if (max_rej < 0) break;                                  // single attempt: report the rejection
+        if (rejects > max_rej) { rc = fail(h, KSFD_EREJECT, "step rejected %d times at t=%g", rejects, *t); break; }
+        if ((rc = halo(h, h->u))) goto out;
+    }
+out:
+    prof_resolve(h);
+    st.bytes = h->bytes_acc - bytes0;
+    st.rhs_evals = (int32_t)(h->prof.launches[KC_RHS] - rhs0);
+    st.jvp_evals = (int32_t)(h->prof.launches[KC_JVP] - jvp0);
+    if (stats) *stats = st;
+    return rc;
+}
+
+extern "C" int ksfd_get_last_error_vector(ksfd_handle *h, double *eh, int32_t layout)
+{
+    if (!h || !eh) return KSFD_EINVAL;
+    if (!h->have_err) return fail(h, KSFD_EINVAL, "no step has been attempted yet");
+    hipSetDevice(h->device);
+    return download(h, h->errv, layout, eh);
+}
+
+extern "C" int ksfd_set_profiling(ksfd_handle *h, int32_t on)
+{
+    if (!h) return KSFD_EINVAL;
+    prof_resolve(h);
+    h->profiling = on != 0;
+    return KSFD_OK;
+}
+extern "C" int ksfd_get_profile(ksfd_handle *h, ksfd_profile *p, int32_t reset)
+{
+    if (!h || !p) return KSFD_EINVAL;
+    prof_resolve(h);
+    *p = h->prof;
+    if (reset) memset(&h->prof, 0, sizeof h->prof);
+    return KSFD_OK;
+}
+extern "C" int ksfd_synchronize(ksfd_handle *h)
+{
+    if (!h) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg)
+{
+    if (!h) return KSFD_EINVAL;
+    if (use_fused >= 0) h->use_fused = use_fused;
+    if (yseg > 0) h->yseg = yseg;
+    return KSFD_OK;
+}
+
+// Raw timing of one kernel class on the current state, HIP events on the compute stream.
+// cls: KC_RHS, KC_JVP, KC_MULTIDOT (k = 8 basis vectors), KC_GSUPDATE (k = 8), KC_LINCOMB (3 inputs).
+extern "C" int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms, double *bytes_per_launch)
+{
+    if (!h || reps < 1 || !avg_ms) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    hipEvent_t a, b;
+    HIPCHK(h, hipEventCreate(&a));
+    HIPCHK(h, hipEventCreate(&b));
+    const bool was = h->profiling;
+    h->profiling = false;
+    int rc = KSFD_OK;
+    double by = 0.0;
+    auto one = [&]() -> int {
+        const double b0 = h->bytes_acc;
+        int r = KSFD_OK;
+        double coef[KSFD_MAXDOT] = { 0 };
+        switch (cls) {
+        case KC_RHS: r = op_rhs(h, h->u, -1, h->t3); break;
+        case KC_JVP: r = op_jvp(h, h->u, h->Y, 1, 1.0, h->t3); break;
+        case KC_MULTIDOT: {
+            Scope sc(h, KC_MULTIDOT, vbytes(h, 9));
+            hipLaunchKernelGGL((k_multidot<8>), dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)h->t3, (const double *)h->V, h->vlen, 8, h->part);
+        } break;
+        case KC_GSUPDATE: r = op_gs_update(h, h->t3, h->V, 8, coef, 1.0); break;
+        case KC_LINCOMB: { const double *xs[3] = { h->u, h->Y, h->Y + h->vlen }; double aa[3] = { 1.0, 0.5, 0.25 }; r = op_lincomb(h, 3, xs, aa, h->t3); } break;
+        default: r = fail(h, KSFD_EINVAL, "bench_kernel: class %d not benchable", cls);
+        }
+        by = h->bytes_acc - b0;
+        return r;
+    };
+    if ((rc = halo(h, h->u))) goto done;
+    for (int i = 0; i < 3 && !rc; i++) rc = one();
+    if (rc) goto done;
+    hipEventRecord(a, h->st);
+    for (int i = 0; i < reps && !rc; i++) rc = one();
+    hipEventRecord(b, h->st);
+    if (hipEventSynchronize(b) != hipSuccess) rc = fail(h, KSFD_EHIP, "event sync failed");
+    if (!rc) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, a, b);
+        *avg_ms = ms / reps;
+        if (bytes_per_launch) *bytes_per_launch = by;
+    }
+done:
+    h->profiling = was;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    return rc;
+}

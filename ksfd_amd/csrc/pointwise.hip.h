@@ -1,0 +1,292 @@
+// Pointwise physics + BLAS-1 style kernels (gfx950, wave64).
+// All vectors use the slab layout of params.h; kernels touch the owned interior only:
+//   element (c, p), p in [0, nloc)  ->  base[c*plane + ng*inner + p]
+#pragma once
+#include <hip/hip_runtime.h>
+#include "params.h"
+
+#define KSFD_WAVE 64
+#define KSFD_BLOCK 256
+#define KSFD_MAXDOT 34
+
+// ---------------------------------------------------------------------------------------------
+// Derivatives.groom (KSFD/ksfdsym.py:888-900): x = max(x, lo), NaN -> lo.  One compare covers both.
+__device__ __forceinline__ double ksfd_clamp(double x, double lo) { return !(x >= lo) ? lo : x; }
+
+// Free energy G(rho,U) = sum_g -beta_g log(alpha_g + sum_l w_gl U_gl) + Vcap(rho) + s2 log(rho)
+// (KSFD/ksfdsym.py:983-990, ksfdligand.py:527-547, ksfdsoln.py:147-161) and, for the Jacobian
+// action, its partials G_rho and G_Ul (closed forms: SURVEY.md section 0).
+// NL is a compile-time ligand count so U[]/GU[] stay in registers.
+template <int NL, bool DERIV>
+__device__ __forceinline__ void ksfd_G(const KPhys &P, double rho, const double (&U)[NL], double &G,
+                                       double &Grho, double (&GU)[NL])
+{
+    double g = 0.0;
+    for (int q = 0; q < P.ngroups; q++) {        // wave-uniform loop, constants come from SGPRs
+        double s = P.grp_alpha[q];
+#pragma unroll
+        for (int l = 0; l < NL; l++) s += (P.lig_group[l] == q) ? P.lig_w[l] * U[l] : 0.0;
+        g -= P.grp_beta[q] * log(s);
+        if (DERIV) {
+            double nb = -P.grp_beta[q] / s;
+#pragma unroll
+            for (int l = 0; l < NL; l++) GU[l] = (P.lig_group[l] == q) ? nb * P.lig_w[l] : GU[l];
+        }
+    }
+    double th = tanh((rho - P.rhomax) * P.inv_cushion);
+    double cap, dcap;
+    if (P.cap_kind == 1) {                        // witch
+        double r = rho * P.inv_rhomax;
+        cap = P.ms * (th + 1.0) * r;
+        dcap = P.ms * ((1.0 - th * th) * r * P.inv_cushion + (th + 1.0) * P.inv_rhomax);
+    } else {                                      // tophat
+        cap = P.ms * (th + 1.0);
+        dcap = P.ms * (1.0 - th * th) * P.inv_cushion;
+    }
+    G = g + cap + P.s2 * log(rho);
+    if (DERIV) Grho = P.s2 / rho + dcap;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions: wave64 shuffle tree, then one LDS hop across the 4 waves of a 256-thread block.
+__device__ __forceinline__ double ksfd_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = KSFD_WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, KSFD_WAVE);
+    return v;
+}
+__device__ __forceinline__ double ksfd_wave_max(double v)
+{
+#pragma unroll
+    for (int o = KSFD_WAVE / 2; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, KSFD_WAVE));
+    return v;
+}
+
+// Vector addressing helper: one blockIdx.y per field plane.
+struct KVec {
+    long long plane, off, nloc;   // off = ng*inner
+    int nf;                       // number of field planes (F)
+};
+
+// out = sum_t a[t] * x[t]   (NT <= 6 inputs; out may alias any x[t]).  Used for the ROSW stage
+// vectors (VecMAXPY/VecWAXPY in PETSc's TSStep_RosW) and the GMRES solution update.
+struct KLin {
+    const double *x[6];
+    double a[6];
+};
+template <int NT>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_lincomb(KVec g, KLin L, double *out)
+{
+    const long long base = (long long)blockIdx.y * g.plane + g.off;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) s += L.a[t] * L.x[t][base + p];
+        out[base + p] = s;
+    }
+}
+
+// Krylov dot products: d[i] = <w, V_i> for i < k, and d[k] = <w, w>, in ONE pass over w.
+// V_i = V + i*vstride.  Block partials go to part[i*nblk + b]; k_reduce_rows finishes them
+// in a fixed order (bitwise reproducible; no float atomics).
+template <int KMAX>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_multidot(KVec g, const double *__restrict__ w,
+                                                         const double *__restrict__ V, long long vstride,
+                                                         int k, double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE][KMAX + 1];
+    double acc[KMAX + 1];
+#pragma unroll
+    for (int i = 0; i <= KMAX; i++) acc[i] = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (int c = 0; c < g.nf; c++) {
+        const long long base = (long long)c * g.plane + g.off;
+        for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
+            const double wv = w[base + p];
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k) acc[i] += wv * V[(long long)i * vstride + base + p];
+            acc[KMAX] += wv * wv;
+        }
+    }
+    const int lane = threadIdx.x & (KSFD_WAVE - 1), wv_ = threadIdx.x / KSFD_WAVE;
+#pragma unroll
+    for (int i = 0; i <= KMAX; i++) {
+        if (i < k || i == KMAX) {
+            double s = ksfd_wave_sum(acc[i]);
+            if (lane == 0) red[wv_][i] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= KMAX) {
+        int i = threadIdx.x;
+        if (i < k || i == KMAX) {
+            double s = 0.0;
+            for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) s += red[q][i];
+            int row = (i == KMAX) ? k : i;
+            part[(long long)row * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+// out[r] = reduce_b part[r*nblk + b]  (op 0 sum, 1 max); one block per row.
+__global__ void __launch_bounds__(KSFD_BLOCK) k_reduce_rows(const double *__restrict__ part, int nblk, int op,
+                                                            double *__restrict__ out)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE];
+    const double *row = part + (long long)blockIdx.x * nblk;
+    double s = op ? -1.0e300 : 0.0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s = op ? fmax(s, row[b]) : s + row[b];
+    s = op ? ksfd_wave_max(s) : ksfd_wave_sum(s);
+    if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red[threadIdx.x / KSFD_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int q = 1; q < KSFD_BLOCK / KSFD_WAVE; q++) t = op ? fmax(t, red[q]) : t + red[q];
+        out[blockIdx.x] = t;
+    }
+}
+
+// Gram-Schmidt update fused with the normalisation:  w = (w - sum_{i<k} h[i] V_i) * scale
+struct KCoef {
+    double h[KSFD_MAXDOT];
+};
+template <int KMAX>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_gs_update(KVec g, double *__restrict__ w,
+                                                          const double *__restrict__ V, long long vstride, int k,
+                                                          KCoef C, double scale)
+{
+    const long long base = (long long)blockIdx.y * g.plane + g.off;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
+        double s = w[base + p];
+#pragma unroll
+        for (int i = 0; i < KMAX; i++)
+            if (i < k) s -= C.h[i] * V[(long long)i * vstride + base + p];
+        w[base + p] = s * scale;
+    }
+}
+
+// x += sum_{i<k} y[i] V_i   (GMRES solution update)
+template <int KMAX>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_basis_axpy(KVec g, double *__restrict__ x,
+                                                           const double *__restrict__ V, long long vstride, int k,
+                                                           KCoef C, double beta)
+{
+    const long long base = (long long)blockIdx.y * g.plane + g.off;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
+        double s = beta == 0.0 ? 0.0 : beta * x[base + p];
+#pragma unroll
+        for (int i = 0; i < KMAX; i++)
+            if (i < k) s += C.h[i] * V[(long long)i * vstride + base + p];
+        x[base + p] = s;
+    }
+}
+
+// Step completion (PETSc TSEvaluateStep_RosW + TSErrorWeightedNorm, restated):
+//   unew = u + sum_j bt[j] Y_j ;  err = sum_j (b2t[j]-bt[j]) Y_j ;
+//   partial sum of (err / (atol + rtol*max(|unew|, |unew+err|)))^2.
+// Writes unew over u (the caller keeps a rollback copy) and, if errout != NULL, err.
+__global__ void __launch_bounds__(KSFD_BLOCK) k_rosw_finish(KVec g, double *__restrict__ u,
+                                                            const double *__restrict__ Y, long long ystride,
+                                                            double bt0, double bt1, double bt2, double bt3,
+                                                            double e0, double e1, double e2, double e3,
+                                                            double atol, double rtol, double *__restrict__ errout,
+                                                            double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE];
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (int c = 0; c < g.nf; c++) {
+        const long long base = (long long)c * g.plane + g.off;
+        for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
+            const double y0 = Y[base + p], y1 = Y[ystride + base + p], y2 = Y[2 * ystride + base + p],
+                         y3 = Y[3 * ystride + base + p];
+            const double un = u[base + p] + (bt0 * y0 + bt1 * y1 + bt2 * y2 + bt3 * y3);
+            const double er = e0 * y0 + e1 * y1 + e2 * y2 + e3 * y3;
+            const double tol = atol + rtol * fmax(fabs(un), fabs(un + er));
+            const double q = er / tol;
+            acc += q * q;
+            u[base + p] = un;
+            if (errout) errout[base + p] = er;
+        }
+    }
+    acc = ksfd_wave_sum(acc);
+    if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red[threadIdx.x / KSFD_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) t += red[q];
+        part[blockIdx.x] = t;
+    }
+}
+
+// KSFDTS.groom on the stored state (KSFD/ksfdts.py:231-237)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_groom(KVec g, double *__restrict__ u, double rhomin, double Umin)
+{
+    const long long base = (long long)blockIdx.y * g.plane + g.off;
+    const double lo = blockIdx.y == 0 ? rhomin : Umin;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride)
+        u[base + p] = ksfd_clamp(u[base + p], lo);
+}
+
+// sum of plane 0 (count_worms, KSFD/ksfdts.py:239-246)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_sum_rho(KVec g, const double *__restrict__ u, double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE];
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) acc += u[g.off + p];
+    acc = ksfd_wave_sum(acc);
+    if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red[threadIdx.x / KSFD_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) t += red[q];
+        part[blockIdx.x] = t;
+    }
+}
+
+// rho *= factor (conserve_worms) or rho[p] *= f[p] (add_variance)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_mul_rho(KVec g, double *__restrict__ u, const double *__restrict__ f,
+                                                        double scalar)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride)
+        u[g.off + p] *= f ? f[p] : scalar;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-layout <-> device-layout permutations (run on the device, staged through a flat buffer).
+// layout 0 PETSc: c + F*p ; layout 1 SoA: c*nloc + p ; layout 2 HDF5: C order over (c, x, y[, z]).
+__device__ __forceinline__ long long ksfd_host_index(const KGeom &G, int layout, int c, long long p)
+{
+    if (layout == 0) return c + (long long)G.F * p;
+    if (layout == 1) return (long long)c * G.nloc + p;
+    long long i = p % G.nx, r = p / G.nx;
+    if (G.dim == 1) return (long long)c * G.nx + i;
+    long long j = r % G.ny, k = r / G.ny;
+    if (G.dim == 2) return ((long long)c * G.nx + i) * G.ny + j;
+    return (((long long)c * G.nx + i) * G.ny + j) * G.nz + k;
+}
+__global__ void __launch_bounds__(KSFD_BLOCK) k_from_host_layout(KGeom G, int layout, const double *__restrict__ flat,
+                                                                 double *__restrict__ dev, long long devplane,
+                                                                 long long devoff)
+{
+    const int c = blockIdx.y;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride)
+        dev[(long long)c * devplane + devoff + p] = flat[ksfd_host_index(G, layout, c, p)];
+}
+__global__ void __launch_bounds__(KSFD_BLOCK) k_to_host_layout(KGeom G, int layout, const double *__restrict__ dev,
+                                                               long long devplane, long long devoff,
+                                                               double *__restrict__ flat)
+{
+    const int c = blockIdx.y;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride)
+        flat[ksfd_host_index(G, layout, c, p)] = dev[(long long)c * devplane + devoff + p];
+}

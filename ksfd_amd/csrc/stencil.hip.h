@@ -1,0 +1,488 @@
+// Stencil kernels: RHS (Derivatives.dfdt), Jacobian action, CFL velocity.
+//
+// Two families:
+//  * "generic" (1-D / 2-D / 3-D, any size): a pointwise pass writes G (and dG) over the local
+//    slab including ghost units, then a one-thread-per-point pass applies the 4th-order star
+//    (5/9/13 points) with direct, L1/L2-served neighbour loads.  Simple; used for 1-D, 3-D and
+//    odd sizes, and as the in-library cross-check of the fused kernels.
+//  * "fused 2-D" (the 4096^2 headline path): one pass, no G array.  Each wave64 owns a strip of
+//    128 columns (2 per lane, 16-B loads, 124 of them outputs) and marches down a segment of rows
+//    holding a 5-row register window of rho, G, U_l; G is evaluated once per loaded point; the
+//    x-neighbours come from wave shuffles, the y-neighbours from the window.  Compulsory HBM
+//    traffic only: read F planes, write F planes (+4 halo rows per segment, L2 hits).
+#pragma once
+#include "pointwise.hip.h"
+
+struct KSrc {
+    const double *p[KSFD_MAXL + 1];   // dense nloc-sized source planes (no ghosts) or NULL
+};
+
+// ---------------------------------------------------------------------------------------------
+// generic family
+// ---------------------------------------------------------------------------------------------
+
+// G (and dG = G_rho*v_rho + sum G_Ul*v_Ul) at every point of the slab incl. ghosts.
+template <int NL, bool DERIV>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_gfield(KGeom G, KPhys P, const double *__restrict__ u,
+                                                       const double *__restrict__ v, double *__restrict__ Gout,
+                                                       double *__restrict__ dGout)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < G.plane; e += stride) {
+        double rho = ksfd_clamp(u[e], P.rhomin);
+        double U[NL], GU[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) U[l] = ksfd_clamp(u[(long long)(l + 1) * G.plane + e], P.Umin);
+        double g, gr = 0.0;
+        ksfd_G<NL, DERIV>(P, rho, U, g, gr, GU);
+        Gout[e] = g;
+        if (DERIV) {
+            double d = gr * v[e];
+#pragma unroll
+            for (int l = 0; l < NL; l++) d += GU[l] * v[(long long)(l + 1) * G.plane + e];
+            dGout[e] = d;
+        }
+    }
+}
+
+// neighbour addressing for the generic kernels: offsets (relative to a field plane base) of the
+// point and its +-1, +-2 neighbours along axis a.
+struct KNbr {
+    long long c, m2, m1, p1, p2;
+};
+__device__ __forceinline__ long long ksfd_wrap(long long i, long long n)
+{
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+__device__ __forceinline__ void ksfd_decode(const KGeom &G, long long p, long long &i, long long &j, long long &k)
+{
+    i = p % G.nx;
+    long long r = p / G.nx;
+    j = (G.dim >= 2) ? r % G.ny : 0;
+    k = (G.dim >= 3) ? r / G.ny : 0;
+}
+__device__ __forceinline__ KNbr ksfd_nbr(const KGeom &G, int a, long long i, long long j, long long k)
+{
+    // coordinates along the slow axis are local (0..sloc-1); ghosts sit at -2,-1 and sloc,sloc+1
+    long long idx[3] = { i, j, k };
+    long long ext[3] = { G.nx, G.ny, G.nz };
+    long long str[3] = { 1, G.nx, G.nx * G.ny };
+    const int slow = G.dim - 1;
+    long long base = 0;
+    for (int d = 0; d < G.dim; d++)
+        if (d != a) base += (d == slow ? idx[d] + G.ng : idx[d]) * str[d];
+    KNbr n;
+    long long q[5];
+#pragma unroll
+    for (int m = -2; m <= 2; m++) {
+        long long x = idx[a] + m;
+        if (a == slow) x = G.wrap_slow ? ksfd_wrap(x, ext[a]) : x + G.ng;
+        else x = ksfd_wrap(x, ext[a]);
+        q[m + 2] = base + x * str[a];
+    }
+    n.m2 = q[0]; n.m1 = q[1]; n.c = q[2]; n.p1 = q[3]; n.p2 = q[4];
+    return n;
+}
+
+// Derivatives.dfdt (KSFD/ksfdsym.py:902-940) given the G plane:
+//   out_rho = sum_a D1a(rho) D1a(G) + rho sum_a D2a(G) + src      (:531-571, :763-812)
+//   out_Ul  = -gamma U + s rho + D sum_a D2a(U) + src             (:583-613)
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_rhs_generic(KGeom G, KPhys P, const double *__restrict__ u,
+                                                            const double *__restrict__ Gb, KSrc src,
+                                                            double *__restrict__ out)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
+        long long i, j, k;
+        ksfd_decode(G, p, i, j, k);
+        double acc = 0.0, lapG = 0.0, rho0 = 0.0;
+        double lapU[NL], U0[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) lapU[l] = 0.0;
+        for (int a = 0; a < G.dim; a++) {
+            KNbr n = ksfd_nbr(G, a, i, j, k);
+            double r_m2 = ksfd_clamp(u[n.m2], P.rhomin), r_m1 = ksfd_clamp(u[n.m1], P.rhomin),
+                   r_p1 = ksfd_clamp(u[n.p1], P.rhomin), r_p2 = ksfd_clamp(u[n.p2], P.rhomin);
+            rho0 = ksfd_clamp(u[n.c], P.rhomin);
+            double g_m2 = Gb[n.m2], g_m1 = Gb[n.m1], g_0 = Gb[n.c], g_p1 = Gb[n.p1], g_p2 = Gb[n.p2];
+            acc += (KSFD_D1(r_m2, r_m1, r_p1, r_p2) * P.inv_h[a]) * (KSFD_D1(g_m2, g_m1, g_p1, g_p2) * P.inv_h[a]);
+            lapG += KSFD_D2(g_m2, g_m1, g_0, g_p1, g_p2) * P.inv_h2[a];
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const double *U = u + (long long)(l + 1) * G.plane;
+                double c0 = ksfd_clamp(U[n.c], P.Umin);
+                U0[l] = c0;
+                lapU[l] += KSFD_D2(ksfd_clamp(U[n.m2], P.Umin), ksfd_clamp(U[n.m1], P.Umin), c0,
+                                   ksfd_clamp(U[n.p1], P.Umin), ksfd_clamp(U[n.p2], P.Umin)) * P.inv_h2[a];
+            }
+        }
+        const long long o = (long long)G.ng * G.inner + p;
+        double r = acc + rho0 * lapG;
+        if (src.p[0]) r += src.p[0][p];
+        out[o] = r;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            double w = -P.lig_gamma[l] * U0[l] + P.lig_s[l] * rho0 + P.lig_D[l] * lapU[l];
+            if (src.p[l + 1]) w += src.p[l + 1][p];
+            out[(long long)(l + 1) * G.plane + o] = w;
+        }
+    }
+}
+
+// Jacobian action at the (clamped) state u on v, given G and dG planes.  mode 0: out = J v,
+// mode 1: out = shift*v - J v  (the IJacobian of KSFD/ksfdts.py:598-640 applied matrix-free).
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, const double *__restrict__ u,
+                                                            const double *__restrict__ v,
+                                                            const double *__restrict__ Gb,
+                                                            const double *__restrict__ dGb, int mode, double shift,
+                                                            double *__restrict__ out)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
+        long long i, j, k;
+        ksfd_decode(G, p, i, j, k);
+        double acc = 0.0, lapG = 0.0, lapdG = 0.0, rho0 = 0.0, v0 = 0.0;
+        double lapV[NL], V0[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) lapV[l] = 0.0;
+        for (int a = 0; a < G.dim; a++) {
+            KNbr n = ksfd_nbr(G, a, i, j, k);
+            double r_m2 = ksfd_clamp(u[n.m2], P.rhomin), r_m1 = ksfd_clamp(u[n.m1], P.rhomin),
+                   r_p1 = ksfd_clamp(u[n.p1], P.rhomin), r_p2 = ksfd_clamp(u[n.p2], P.rhomin);
+            rho0 = ksfd_clamp(u[n.c], P.rhomin);
+            v0 = v[n.c];
+            double d1r = KSFD_D1(r_m2, r_m1, r_p1, r_p2) * P.inv_h[a];
+            double d1v = KSFD_D1(v[n.m2], v[n.m1], v[n.p1], v[n.p2]) * P.inv_h[a];
+            double d1g = KSFD_D1(Gb[n.m2], Gb[n.m1], Gb[n.p1], Gb[n.p2]) * P.inv_h[a];
+            double d1e = KSFD_D1(dGb[n.m2], dGb[n.m1], dGb[n.p1], dGb[n.p2]) * P.inv_h[a];
+            acc += d1v * d1g + d1r * d1e;
+            lapG += KSFD_D2(Gb[n.m2], Gb[n.m1], Gb[n.c], Gb[n.p1], Gb[n.p2]) * P.inv_h2[a];
+            lapdG += KSFD_D2(dGb[n.m2], dGb[n.m1], dGb[n.c], dGb[n.p1], dGb[n.p2]) * P.inv_h2[a];
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const double *V = v + (long long)(l + 1) * G.plane;
+                V0[l] = V[n.c];
+                lapV[l] += KSFD_D2(V[n.m2], V[n.m1], V[n.c], V[n.p1], V[n.p2]) * P.inv_h2[a];
+            }
+        }
+        const long long o = (long long)G.ng * G.inner + p;
+        double jr = acc + v0 * lapG + rho0 * lapdG;
+        out[o] = mode ? shift * v0 - jr : jr;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            double ju = -P.lig_gamma[l] * V0[l] + P.lig_s[l] * v0 + P.lig_D[l] * lapV[l];
+            out[(long long)(l + 1) * G.plane + o] = mode ? shift * V0[l] - ju : ju;
+        }
+    }
+}
+
+// Derivatives.velocity (KSFD/ksfdsym.py:1158-1209): v_a = D1a(G).  Writes dense dim*nloc planes when
+// vel != NULL and per-block per-axis max|v_a| partials (CFL_step, KSFD/ksfdts.py:302-319) when part != NULL.
+__global__ void __launch_bounds__(KSFD_BLOCK) k_velocity(KGeom G, KPhys P, const double *__restrict__ Gb,
+                                                         double *__restrict__ vel, double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE][3];
+    double mx[3] = { 0.0, 0.0, 0.0 };
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
+        long long i, j, k;
+        ksfd_decode(G, p, i, j, k);
+        for (int a = 0; a < G.dim; a++) {
+            KNbr n = ksfd_nbr(G, a, i, j, k);
+            double d = KSFD_D1(Gb[n.m2], Gb[n.m1], Gb[n.p1], Gb[n.p2]) * P.inv_h[a];
+            if (vel) vel[(long long)a * G.nloc + p] = d;
+            mx[a] = fmax(mx[a], fabs(d));
+        }
+    }
+    if (part) {
+        for (int a = 0; a < 3; a++) {
+            double m = ksfd_wave_max(mx[a]);
+            if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red[threadIdx.x / KSFD_WAVE][a] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double m = 0.0;
+            for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) m = fmax(m, red[q][threadIdx.x]);
+            part[(long long)threadIdx.x * gridDim.x + blockIdx.x] = m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused 2-D family
+// ---------------------------------------------------------------------------------------------
+#define KSFD_STRIP_OUT 124          // output columns per wave strip (128 loaded, 2 halo each side)
+
+struct KStrips {
+    int nstrips;      // ceil(nx / 124), strips balanced to even widths
+    int nseg;         // ceil(sloc / yseg)
+    int yseg;
+    int nblocks;      // launch grid (multiple of 8 for the XCD remap)
+};
+
+// blockIdx -> logical block so that each XCD (blocks are dealt round-robin over the 8 XCDs)
+// works on one contiguous band of row segments: neighbouring strips/segments then share an L2.
+__device__ __forceinline__ int ksfd_xcd_remap(int b, int nblocks)
+{
+    const int per = nblocks >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+__device__ __forceinline__ long long ksfd_rowoff(const KGeom &G, long long r)
+{
+    // r may be -2..sloc+1
+    if (G.wrap_slow) {
+        r %= G.sloc;
+        if (r < 0) r += G.sloc;
+        return r * G.nx;
+    }
+    return (r + G.ng) * G.nx;
+}
+
+__device__ __forceinline__ double2 ksfd_ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+__device__ __forceinline__ void ksfd_st2(double *p, double a, double b)
+{
+    *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+}
+
+// x-neighbours of a 2-column pair through wave shuffles.  For the pair (a0,a1) at columns (c,c+1):
+// left lane holds (c-2,c-1), right lane (c+2,c+3).
+struct KX {
+    double l0, l1, r0, r1;
+};
+__device__ __forceinline__ KX ksfd_xnb(double a0, double a1)
+{
+    KX x;
+    x.l0 = __shfl_up(a0, 1, KSFD_WAVE);
+    x.l1 = __shfl_up(a1, 1, KSFD_WAVE);
+    x.r0 = __shfl_down(a0, 1, KSFD_WAVE);
+    x.r1 = __shfl_down(a1, 1, KSFD_WAVE);
+    return x;
+}
+// h*d/dx and h^2*d2/dx2 for both points of the pair
+__device__ __forceinline__ void ksfd_dx(double a0, double a1, const KX &x, double &d1_0, double &d1_1)
+{
+    d1_0 = KSFD_D1(x.l0, x.l1, a1, x.r0);
+    d1_1 = KSFD_D1(x.l1, a0, x.r0, x.r1);
+}
+__device__ __forceinline__ void ksfd_dxx(double a0, double a1, const KX &x, double &d2_0, double &d2_1)
+{
+    d2_0 = KSFD_D2(x.l0, x.l1, a0, a1, x.r0);
+    d2_1 = KSFD_D2(x.l1, a0, a1, x.r0, x.r1);
+}
+
+struct KWaveJob {
+    long long c0;       // first of this lane's two columns (wrapped)
+    long long r0, r1;   // row segment [r0, r1)
+    bool store;
+    bool valid;
+};
+__device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips &S)
+{
+    KWaveJob J;
+    const int lane = threadIdx.x & (KSFD_WAVE - 1);
+    const long long wid = (long long)ksfd_xcd_remap(blockIdx.x, S.nblocks) * (KSFD_BLOCK / KSFD_WAVE) + (threadIdx.x >> 6);
+    J.valid = wid < (long long)S.nstrips * S.nseg;
+    const int strip = (int)(wid % S.nstrips);
+    const long long seg = wid / S.nstrips;
+    const long long half = G.nx >> 1;
+    const long long xs = 2 * ((long long)strip * half / S.nstrips);
+    const long long xe = 2 * ((long long)(strip + 1) * half / S.nstrips);
+    long long c = xs - 2 + 2 * lane;
+    c %= G.nx;
+    if (c < 0) c += G.nx;
+    J.c0 = c;
+    J.store = lane >= 1 && lane <= (int)((xe - xs) >> 1);
+    J.r0 = seg * S.yseg;
+    J.r1 = J.r0 + S.yseg < G.sloc ? J.r0 + S.yseg : G.sloc;
+    return J;
+}
+
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KStrips S, const double *__restrict__ u,
+                                                            KSrc src, double *__restrict__ out)
+{
+    const KWaveJob J = ksfd_wave_job(G, S);
+    if (!J.valid) return;                       // whole waves only; the kernel has no block barrier
+    // 5-row windows, two columns per lane: slot s <-> row (r - 2 + s)
+    double rw[5][2], gw[5][2], uw[NL][5][2];
+    double nr[2], nu[NL][2];                   // raw values of the row being prefetched
+
+    auto load_row = [&](long long r) {
+        const long long o = ksfd_rowoff(G, r) + J.c0;
+        double2 t = ksfd_ld2(u + o);
+        nr[0] = t.x; nr[1] = t.y;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            double2 q = ksfd_ld2(u + (long long)(l + 1) * G.plane + o);
+            nu[l][0] = q.x; nu[l][1] = q.y;
+        }
+    };
+    auto push_row = [&]() {                     // shift windows up one row, append the prefetched row
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                rw[s][e] = rw[s + 1][e];
+                gw[s][e] = gw[s + 1][e];
+#pragma unroll
+                for (int l = 0; l < NL; l++) uw[l][s][e] = uw[l][s + 1][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            double U[NL], GU[NL], gr;
+            double rho = ksfd_clamp(nr[e], P.rhomin);
+#pragma unroll
+            for (int l = 0; l < NL; l++) { U[l] = ksfd_clamp(nu[l][e], P.Umin); uw[l][4][e] = U[l]; }
+            ksfd_G<NL, false>(P, rho, U, gw[4][e], gr, GU);
+            rw[4][e] = rho;
+        }
+    };
+
+    // prologue: rows r0-2 .. r0+1 fill slots 1..4 after four pushes
+    for (int q = -2; q <= 1; q++) { load_row(J.r0 + q); push_row(); }
+    load_row(J.r0 + 2);
+    for (long long r = J.r0; r < J.r1; r++) {
+        push_row();                             // window now centred on row r
+        if (r + 1 < J.r1) load_row(r + 3);      // prefetch for the next iteration
+        // x neighbours of the centre row
+        const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
+        const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
+        double d1rx[2], d1gx[2], d2gx[2];
+        ksfd_dx(rw[2][0], rw[2][1], xr, d1rx[0], d1rx[1]);
+        ksfd_dx(gw[2][0], gw[2][1], xg, d1gx[0], d1gx[1]);
+        ksfd_dxx(gw[2][0], gw[2][1], xg, d2gx[0], d2gx[1]);
+        double res[NL + 1][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double d1ry = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * P.inv_h[1];
+            const double d1gy = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * P.inv_h[1];
+            const double d2gy = KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[1];
+            res[0][e] = (d1rx[e] * P.inv_h[0]) * (d1gx[e] * P.inv_h[0]) + d1ry * d1gy +
+                        rw[2][e] * (d2gx[e] * P.inv_h2[0] + d2gy);
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const KX xu = ksfd_xnb(uw[l][2][0], uw[l][2][1]);
+            double d2ux[2];
+            ksfd_dxx(uw[l][2][0], uw[l][2][1], xu, d2ux[0], d2ux[1]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double d2uy = KSFD_D2(uw[l][0][e], uw[l][1][e], uw[l][2][e], uw[l][3][e], uw[l][4][e]) * P.inv_h2[1];
+                res[l + 1][e] = -P.lig_gamma[l] * uw[l][2][e] + P.lig_s[l] * rw[2][e] +
+                                P.lig_D[l] * (d2ux[e] * P.inv_h2[0] + d2uy);
+            }
+        }
+        if (J.store) {
+            const long long pi = r * G.nx + J.c0;                 // dense interior index
+            const long long o = (long long)G.ng * G.inner + pi;   // offset inside a plane
+#pragma unroll
+            for (int c = 0; c <= NL; c++) {
+                double a = res[c][0], b = res[c][1];
+                if (src.p[c]) { double2 s = ksfd_ld2(src.p[c] + pi); a += s.x; b += s.y; }
+                ksfd_st2(out + (long long)c * G.plane + o, a, b);
+            }
+        }
+    }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_fused(KGeom G, KPhys P, KStrips S, const double *__restrict__ u,
+                                                            const double *__restrict__ v, int mode, double shift,
+                                                            double *__restrict__ out)
+{
+    const KWaveJob J = ksfd_wave_job(G, S);
+    if (!J.valid) return;
+    double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
+    double nr[2], nv[2], nu[NL][2], nz[NL][2];
+
+    auto load_row = [&](long long r) {
+        const long long o = ksfd_rowoff(G, r) + J.c0;
+        double2 t = ksfd_ld2(u + o), w = ksfd_ld2(v + o);
+        nr[0] = t.x; nr[1] = t.y; nv[0] = w.x; nv[1] = w.y;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            double2 q = ksfd_ld2(u + (long long)(l + 1) * G.plane + o);
+            double2 z = ksfd_ld2(v + (long long)(l + 1) * G.plane + o);
+            nu[l][0] = q.x; nu[l][1] = q.y; nz[l][0] = z.x; nz[l][1] = z.y;
+        }
+    };
+    auto push_row = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                rw[s][e] = rw[s + 1][e]; gw[s][e] = gw[s + 1][e];
+                vw[s][e] = vw[s + 1][e]; ew[s][e] = ew[s + 1][e];
+#pragma unroll
+                for (int l = 0; l < NL; l++) zw[l][s][e] = zw[l][s + 1][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            double U[NL], GU[NL], gr;
+            double rho = ksfd_clamp(nr[e], P.rhomin);
+#pragma unroll
+            for (int l = 0; l < NL; l++) U[l] = ksfd_clamp(nu[l][e], P.Umin);
+            ksfd_G<NL, true>(P, rho, U, gw[4][e], gr, GU);
+            double d = gr * nv[e];
+#pragma unroll
+            for (int l = 0; l < NL; l++) { d += GU[l] * nz[l][e]; zw[l][4][e] = nz[l][e]; }
+            rw[4][e] = rho; vw[4][e] = nv[e]; ew[4][e] = d;
+        }
+    };
+
+    for (int q = -2; q <= 1; q++) { load_row(J.r0 + q); push_row(); }
+    load_row(J.r0 + 2);
+    for (long long r = J.r0; r < J.r1; r++) {
+        push_row();
+        if (r + 1 < J.r1) load_row(r + 3);
+        const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
+        const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
+        const KX xv = ksfd_xnb(vw[2][0], vw[2][1]);
+        const KX xe = ksfd_xnb(ew[2][0], ew[2][1]);
+        double d1r[2], d1g[2], d1v[2], d1e[2], d2g[2], d2e[2];
+        ksfd_dx(rw[2][0], rw[2][1], xr, d1r[0], d1r[1]);
+        ksfd_dx(gw[2][0], gw[2][1], xg, d1g[0], d1g[1]);
+        ksfd_dx(vw[2][0], vw[2][1], xv, d1v[0], d1v[1]);
+        ksfd_dx(ew[2][0], ew[2][1], xe, d1e[0], d1e[1]);
+        ksfd_dxx(gw[2][0], gw[2][1], xg, d2g[0], d2g[1]);
+        ksfd_dxx(ew[2][0], ew[2][1], xe, d2e[0], d2e[1]);
+        double res[NL + 1][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double ih0 = P.inv_h[0], ih1 = P.inv_h[1];
+            const double yr = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * ih1;
+            const double yg = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * ih1;
+            const double yv = KSFD_D1(vw[0][e], vw[1][e], vw[3][e], vw[4][e]) * ih1;
+            const double ye = KSFD_D1(ew[0][e], ew[1][e], ew[3][e], ew[4][e]) * ih1;
+            const double lapG = d2g[e] * P.inv_h2[0] + KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[1];
+            const double lapE = d2e[e] * P.inv_h2[0] + KSFD_D2(ew[0][e], ew[1][e], ew[2][e], ew[3][e], ew[4][e]) * P.inv_h2[1];
+            const double jr = (d1v[e] * ih0) * (d1g[e] * ih0) + (d1r[e] * ih0) * (d1e[e] * ih0) + yv * yg + yr * ye +
+                              vw[2][e] * lapG + rw[2][e] * lapE;
+            res[0][e] = mode ? shift * vw[2][e] - jr : jr;
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const KX xz = ksfd_xnb(zw[l][2][0], zw[l][2][1]);
+            double d2z[2];
+            ksfd_dxx(zw[l][2][0], zw[l][2][1], xz, d2z[0], d2z[1]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double lap = d2z[e] * P.inv_h2[0] +
+                                   KSFD_D2(zw[l][0][e], zw[l][1][e], zw[l][2][e], zw[l][3][e], zw[l][4][e]) * P.inv_h2[1];
+                const double ju = -P.lig_gamma[l] * zw[l][2][e] + P.lig_s[l] * vw[2][e] + P.lig_D[l] * lap;
+                res[l + 1][e] = mode ? shift * zw[l][2][e] - ju : ju;
+            }
+        }
+        if (J.store) {
+            const long long o = (long long)G.ng * G.inner + r * G.nx + J.c0;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) ksfd_st2(out + (long long)c * G.plane + o, res[c][0], res[c][1]);
+        }
+    }
+}

@@ -1,0 +1,158 @@
+// Halo / reduction transports behind the slab decomposition (stand-in for the PETSc DMDA ghost
+// exchange and MPI allreduce of the reference: KSFD/ksfdgrid.py:388-411, KSFD/ksfdts.py:310-313).
+//
+//  * RcclTransport: ncclSend/ncclRecv ring-neighbour exchange + ncclAllReduce over xGMI, issued on the
+//    library's compute stream.  librccl is resolved at run time with dlopen (first the copy already
+//    loaded into the process, e.g. by torch), so the single-GPU path carries no RCCL dependency.
+//  * CallbackTransport: the host language does the exchange (mpi4py, torch.distributed/gloo, ...) on
+//    pinned host staging buffers.  Slower, but works with any launcher and on one shared GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string>
+#include <string.h>
+
+#include "../../include/ksfd_hip.h"
+
+struct Transport {
+    virtual ~Transport() {}
+    // fill the 2*ng ghost units of every field plane of vec from the ring neighbours
+    virtual int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) = 0;
+    virtual int allreduce(double *dev, int n, int op, hipStream_t st) = 0;   // op 0 sum, 1 max; in place
+    virtual bool result_on_host() const { return false; }
+    virtual const double *host_result() const { return nullptr; }
+    const std::string &error() const { return err; }
+    std::string err;
+};
+
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(std::string &err)
+    {
+        const char *names[] = { "librccl.so.1", "librccl.so" };
+        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }
+        if (!lib) for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+#define KSFD_SYM(f) f = (decltype(f))dlsym(lib, "nccl" #f); if (!f) { err = "librccl lacks nccl" #f; return false; }
+        KSFD_SYM(CommInitRank) KSFD_SYM(CommDestroy) KSFD_SYM(GroupStart) KSFD_SYM(GroupEnd)
+        KSFD_SYM(Send) KSFD_SYM(Recv) KSFD_SYM(AllReduce) KSFD_SYM(GetErrorString)
+#undef KSFD_SYM
+        return true;
+    }
+};
+
+struct RcclTransport : Transport {
+    RcclApi api;
+    ncclComm_t comm = nullptr;
+    int rank, size;
+    bool init(const ksfd_dist *d)
+    {
+        rank = d->rank; size = d->size;
+        if (!d->nccl_id) { err = "transport 1 needs the 128-byte ncclUniqueId"; return false; }
+        if (!api.load(err)) return false;
+        ncclUniqueId id;
+        memcpy(&id, d->nccl_id, sizeof id);
+        ncclResult_t r = api.CommInitRank(&comm, size, id, rank);
+        if (r != ncclSuccess) { err = std::string("ncclCommInitRank: ") + api.GetErrorString(r); comm = nullptr; return false; }
+        return true;
+    }
+    ~RcclTransport() override { if (comm) api.CommDestroy(comm); }
+    int chk(ncclResult_t r, const char *what)
+    {
+        if (r == ncclSuccess) return 0;
+        err = std::string(what) + ": " + api.GetErrorString(r);
+        return 1;
+    }
+    int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) override
+    {
+        const int lo = (rank + size - 1) % size, hi = (rank + 1) % size;
+        const size_t cnt = (size_t)ng * inner;
+        if (chk(api.GroupStart(), "ncclGroupStart")) return 1;
+        for (int c = 0; c < F; c++) {
+            double *p = vec + (long long)c * plane;
+            // my low rows -> lo neighbour's high ghost; my high rows -> hi neighbour's low ghost.
+            // Receives are posted hi-ghost first so that with size == 2 (lo == hi) the two messages
+            // of the single peer pair up in issue order.
+            if (chk(api.Send(p + (long long)ng * inner, cnt, ncclDouble, lo, comm, st), "ncclSend")) return 1;
+            if (chk(api.Send(p + sloc * inner, cnt, ncclDouble, hi, comm, st), "ncclSend")) return 1;
+            if (chk(api.Recv(p + (sloc + ng) * inner, cnt, ncclDouble, hi, comm, st), "ncclRecv")) return 1;
+            if (chk(api.Recv(p, cnt, ncclDouble, lo, comm, st), "ncclRecv")) return 1;
+        }
+        return chk(api.GroupEnd(), "ncclGroupEnd");
+    }
+    int allreduce(double *dev, int n, int op, hipStream_t st) override
+    {
+        return chk(api.AllReduce(dev, dev, (size_t)n, ncclDouble, op ? ncclMax : ncclSum, comm, st), "ncclAllReduce");
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct CallbackTransport : Transport {
+    ksfd_exchange_fn ex = nullptr;
+    ksfd_allreduce_fn ar = nullptr;
+    void *ctx = nullptr;
+    double *stage = nullptr;      // pinned: [send_lo | send_hi | recv_lo | recv_hi], each F*ng*inner
+    double *hred = nullptr;       // pinned, 64 doubles
+    size_t chunk = 0;
+    bool init(const ksfd_dist *d, int F, long long inner)
+    {
+        ex = d->exchange; ar = d->allreduce; ctx = d->ctx;
+        if (!ex || !ar) { err = "transport 2 needs exchange and allreduce callbacks"; return false; }
+        chunk = (size_t)F * 2 * inner;
+        if (hipHostMalloc((void **)&stage, sizeof(double) * chunk * 4, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&hred, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return false; }
+        return true;
+    }
+    ~CallbackTransport() override { if (stage) hipHostFree(stage); if (hred) hipHostFree(hred); }
+    int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) override
+    {
+        const size_t w = sizeof(double) * (size_t)ng * inner;     // bytes per field per side
+        double *slo = stage, *shi = stage + chunk, *rlo = stage + 2 * chunk, *rhi = stage + 3 * chunk;
+        hipError_t e;
+        e = hipMemcpy2DAsync(slo, w, vec + (long long)ng * inner, sizeof(double) * plane, w, F, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(shi, w, vec + sloc * inner, sizeof(double) * plane, w, F, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { err = std::string("halo D2H: ") + hipGetErrorString(e); return 1; }
+        if (ex(ctx, slo, shi, rlo, rhi, (int64_t)chunk)) { err = "exchange callback reported failure"; return 1; }
+        e = hipMemcpy2DAsync(vec, sizeof(double) * plane, rlo, w, w, F, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(vec + (sloc + ng) * inner, sizeof(double) * plane, rhi, w, w, F, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { err = std::string("halo H2D: ") + hipGetErrorString(e); return 1; }
+        return 0;
+    }
+    int allreduce(double *dev, int n, int op, hipStream_t st) override
+    {
+        hipError_t e = hipMemcpyAsync(hred, dev, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { err = std::string("allreduce D2H: ") + hipGetErrorString(e); return 1; }
+        if (ar(ctx, hred, n, op)) { err = "allreduce callback reported failure"; return 1; }
+        return 0;
+    }
+    bool result_on_host() const override { return true; }
+    const double *host_result() const override { return hred; }
+};
+
+static Transport *make_transport(const ksfd_dist *d, int F, long long inner, std::string &err)
+{
+    if (d->transport == 1) {
+        RcclTransport *t = new RcclTransport();
+        if (!t->init(d)) { err = t->err; delete t; return nullptr; }
+        return t;
+    }
+    if (d->transport == 2) {
+        CallbackTransport *t = new CallbackTransport();
+        if (!t->init(d, F, inner)) { err = t->err; delete t; return nullptr; }
+        return t;
+    }
+    err = "size > 1 needs transport 1 (RCCL) or 2 (callbacks)";
+    return nullptr;
+}

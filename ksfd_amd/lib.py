@@ -1,0 +1,280 @@
+"""ctypes binding of libksfd_hip.so (include/ksfd_hip.h).
+
+This is the binding INTEGRATION.md shows for the reference side.  There is no CPU fallback: if the
+shared library is missing or no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .config import CConfig, ProblemConfig
+from .layout import PETSC, SOA, HDF5  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libksfd_hip.so')
+NKCLASS = 12
+
+OK, EINVAL, EHIP, ENOMEM, ELINEAR, ENAN, EREJECT, ECOMM = range(8)
+
+# kernel classes of ksfd_profile / ksfd_bench_kernel
+KC_RHS, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE, \
+    KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO = range(12)
+
+
+class KSFDError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('ksfd_hip error %d: %s' % (code, msg))
+        self.code = code
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)
+
+
+class CDist(C.Structure):
+    _fields_ = [('rank', C.c_int32), ('size', C.c_int32), ('transport', C.c_int32), ('device', C.c_int32),
+                ('nccl_id', C.c_void_p), ('exchange', EXCHANGE_FN), ('allreduce', ALLREDUCE_FN),
+                ('ctx', C.c_void_p)]
+
+
+class StepOpts(C.Structure):
+    _fields_ = [('rtol', C.c_double), ('atol', C.c_double), ('adapt', C.c_int32), ('max_reject', C.c_int32),
+                ('clip_lo', C.c_double), ('clip_hi', C.c_double), ('dt_min', C.c_double), ('dt_max', C.c_double),
+                ('safety', C.c_double), ('reject_safety', C.c_double),
+                ('ksp_rtol', C.c_double), ('ksp_atol', C.c_double),
+                ('ksp_restart', C.c_int32), ('ksp_max_it', C.c_int32), ('pc_type', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [('accepted', C.c_int32), ('rejections', C.c_int32), ('linear_its', C.c_int32),
+                ('rhs_evals', C.c_int32), ('jvp_evals', C.c_int32), ('reserved', C.c_int32),
+                ('wrms', C.c_double), ('h_used', C.c_double), ('ksp_resid', C.c_double), ('bytes', C.c_double)]
+
+
+class Profile(C.Structure):
+    _fields_ = [('ms', C.c_double * NKCLASS), ('bytes', C.c_double * NKCLASS), ('launches', C.c_int64 * NKCLASS)]
+
+
+_lib = None
+
+# every symbol include/ksfd_hip.h declares (checked by tests/test_abi.py without a GPU)
+ABI_SYMBOLS = [
+    'ksfd_kernel_class_name', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
+    'ksfd_local_range', 'ksfd_local_size', 'ksfd_set_state', 'ksfd_get_state', 'ksfd_device_state',
+    'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
+    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho',
+    'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
+    'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning',
+]
+
+
+def load():
+    """dlopen libksfd_hip.so and declare signatures.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KSFDError(EHIP, 'libksfd_hip.so not built (run `python -c "import __graft_entry__ as g; g.build()"` '
+                              'or `make -C ksfd_amd/csrc`); there is no CPU fallback')
+    L = C.CDLL(LIB_PATH)
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    L.ksfd_kernel_class_name.restype = C.c_char_p
+    L.ksfd_kernel_class_name.argtypes = [C.c_int32]
+    L.ksfd_create.argtypes = [C.POINTER(CConfig), C.POINTER(CDist), C.POINTER(vp)]
+    L.ksfd_destroy.argtypes = [vp]
+    L.ksfd_destroy.restype = None
+    L.ksfd_last_error.argtypes = [vp]
+    L.ksfd_last_error.restype = C.c_char_p
+    L.ksfd_update_params.argtypes = [vp, C.POINTER(CConfig)]
+    L.ksfd_local_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.ksfd_local_size.argtypes = [vp]
+    L.ksfd_local_size.restype = C.c_int64
+    L.ksfd_set_state.argtypes = [vp, dp, C.c_int32]
+    L.ksfd_get_state.argtypes = [vp, dp, C.c_int32]
+    L.ksfd_device_state.argtypes = [vp]
+    L.ksfd_device_state.restype = vp
+    L.ksfd_device_plane_stride.argtypes = [vp]
+    L.ksfd_device_plane_stride.restype = C.c_int64
+    L.ksfd_device_interior_offset.argtypes = [vp]
+    L.ksfd_device_interior_offset.restype = C.c_int64
+    L.ksfd_set_source.argtypes = [vp, C.c_int32, C.c_int32, dp, C.c_int32]
+    L.ksfd_rhs.argtypes = [vp, C.c_double, dp, dp, C.c_int32]
+    L.ksfd_jvp.argtypes = [vp, dp, dp, dp, C.c_int32]
+    L.ksfd_velocity.argtypes = [vp, dp, dp, C.c_int32]
+    L.ksfd_velocity_max.argtypes = [vp, dp]
+    L.ksfd_groom.argtypes = [vp]
+    L.ksfd_count_worms.argtypes = [vp, dp]
+    L.ksfd_scale_rho.argtypes = [vp, C.c_double]
+    L.ksfd_mul_rho.argtypes = [vp, dp]
+    L.ksfd_default_step_opts.argtypes = [C.POINTER(StepOpts)]
+    L.ksfd_default_step_opts.restype = None
+    L.ksfd_step.argtypes = [vp, dp, dp, C.POINTER(StepOpts), C.POINTER(StepStats)]
+    L.ksfd_get_last_error_vector.argtypes = [vp, dp, C.c_int32]
+    L.ksfd_set_profiling.argtypes = [vp, C.c_int32]
+    L.ksfd_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int32]
+    L.ksfd_synchronize.argtypes = [vp]
+    L.ksfd_bench_kernel.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
+    L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def default_step_opts(**kw):
+    o = StepOpts()
+    load().ksfd_default_step_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError('unknown step option %r' % k)
+        setattr(o, k, v)
+    return o
+
+
+class KSFDHip:
+    """Owns one ksfd_handle (one GPU / one slab).  Host arrays are numpy float64, flat, local slab."""
+
+    def __init__(self, cfg: ProblemConfig, dist: CDist = None):
+        self.L = load()
+        self.cfg = cfg
+        self._ccfg = cfg.as_ctypes()
+        self._dist = dist
+        h = C.c_void_p()
+        rc = self.L.ksfd_create(C.byref(self._ccfg), C.byref(dist) if dist is not None else None, C.byref(h))
+        if rc:
+            raise KSFDError(rc, (self.L.ksfd_last_error(None) or b'').decode())
+        self.h = h
+        self.F = cfg.F
+        self.nlocal = int(self.L.ksfd_local_size(h))        # F * local points
+        b, e = C.c_int64(), C.c_int64()
+        self.L.ksfd_local_range(h, C.byref(b), C.byref(e))
+        self.slow_range = (b.value, e.value)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.ksfd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise KSFDError(rc, (self.L.ksfd_last_error(self.h) or b'').decode())
+
+    def _vec(self, a, n=None):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        if a.size != (n if n is not None else self.nlocal):
+            raise ValueError('expected %d doubles, got %d' % (n if n is not None else self.nlocal, a.size))
+        return a
+
+    # ---- state
+    def set_state(self, u, layout=SOA):
+        u = self._vec(u)
+        self._chk(self.L.ksfd_set_state(self.h, _dp(u), layout))
+
+    def get_state(self, layout=SOA):
+        out = np.empty(self.nlocal)
+        self._chk(self.L.ksfd_get_state(self.h, _dp(out), layout))
+        return out
+
+    def update_params(self, cfg: ProblemConfig):
+        self.cfg = cfg
+        self._ccfg = cfg.as_ctypes()
+        self._chk(self.L.ksfd_update_params(self.h, C.byref(self._ccfg)))
+
+    def set_source(self, field, src, stage=-1):
+        if src is None:
+            self._chk(self.L.ksfd_set_source(self.h, stage, field, None, SOA))
+        else:
+            s = self._vec(src, self.nlocal // self.F)
+            self._chk(self.L.ksfd_set_source(self.h, stage, field, _dp(s), SOA))
+
+    # ---- operators
+    def rhs(self, u=None, t=0.0, layout=SOA):
+        out = np.empty(self.nlocal)
+        up = _dp(self._vec(u)) if u is not None else None
+        self._chk(self.L.ksfd_rhs(self.h, float(t), up, _dp(out), layout))
+        return out
+
+    def jvp(self, v, u=None, layout=SOA):
+        out = np.empty(self.nlocal)
+        v = self._vec(v)
+        up = _dp(self._vec(u)) if u is not None else None
+        self._chk(self.L.ksfd_jvp(self.h, up, _dp(v), _dp(out), layout))
+        return out
+
+    def velocity(self, u=None):
+        n = self.cfg.dim * (self.nlocal // self.F)
+        out = np.empty(n)
+        up = _dp(self._vec(u)) if u is not None else None
+        self._chk(self.L.ksfd_velocity(self.h, up, _dp(out), SOA))
+        return out
+
+    def velocity_max(self):
+        v = np.zeros(3)
+        self._chk(self.L.ksfd_velocity_max(self.h, _dp(v)))
+        return v
+
+    # ---- outer-loop helpers
+    def groom(self):
+        self._chk(self.L.ksfd_groom(self.h))
+
+    def count_worms(self):
+        t = C.c_double()
+        self._chk(self.L.ksfd_count_worms(self.h, C.byref(t)))
+        return t.value
+
+    def scale_rho(self, f):
+        self._chk(self.L.ksfd_scale_rho(self.h, float(f)))
+
+    def mul_rho(self, factor):
+        f = self._vec(factor, self.nlocal // self.F)
+        self._chk(self.L.ksfd_mul_rho(self.h, _dp(f)))
+
+    # ---- step
+    def step(self, t, h, opts=None, raise_on_error=True):
+        """One TS.step().  Returns (t_new, h_next, StepStats, rc)."""
+        opts = opts or default_step_opts()
+        tt, hh, st = C.c_double(t), C.c_double(h), StepStats()
+        rc = self.L.ksfd_step(self.h, C.byref(tt), C.byref(hh), C.byref(opts), C.byref(st))
+        if rc and raise_on_error:
+            self._chk(rc)
+        return tt.value, hh.value, st, rc
+
+    def last_error(self):
+        return (self.L.ksfd_last_error(self.h) or b'').decode()
+
+    def last_error_vector(self, layout=SOA):
+        out = np.empty(self.nlocal)
+        self._chk(self.L.ksfd_get_last_error_vector(self.h, _dp(out), layout))
+        return out
+
+    # ---- measurement
+    def set_profiling(self, on=True):
+        self._chk(self.L.ksfd_set_profiling(self.h, int(on)))
+
+    def profile(self, reset=False):
+        p = Profile()
+        self._chk(self.L.ksfd_get_profile(self.h, C.byref(p), int(reset)))
+        names = [self.L.ksfd_kernel_class_name(i).decode() for i in range(NKCLASS)]
+        return {n: dict(ms=p.ms[i], bytes=p.bytes[i], launches=p.launches[i]) for i, n in enumerate(names)}
+
+    def synchronize(self):
+        self._chk(self.L.ksfd_synchronize(self.h))
+
+    def bench_kernel(self, cls, reps=20):
+        ms, by = C.c_double(), C.c_double()
+        self._chk(self.L.ksfd_bench_kernel(self.h, cls, reps, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def set_tuning(self, use_fused=-1, yseg=0):
+        self._chk(self.L.ksfd_set_tuning(self.h, use_fused, yseg))

@@ -461,7 +461,7 @@ def step_1d_manufactured():
     consts = {kv.split('=')[0]: float(kv.split('=')[1]) for kv in extra}
     lig = [x for x in LIG_N2 if not x.startswith('U0_')] + ['U0_1_1=9000.0', 'U0_2_1=9000.0']
     step_case('step_1d_manufactured', 1, [128], [1.0], lig, 'tophat', 26, h=1.0, nsteps=20,
-              source=['rho=' + src], extra=extra, u0_fn=lambda g: exact93(g, 0.0, consts))
+              source=[src], extra=extra, u0_fn=lambda g: exact93(g, 0.0, consts))
     f = os.path.join(HERE, 'step_1d_manufactured.npz')
     z = dict(np.load(f))
     ps, g, d = build(1, [128], [1.0], lig, 'tophat', extra=extra)

@@ -1,0 +1,102 @@
+"""GPU: HIP operators (through the C ABI) vs the golden vectors from the reference and vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden, rel_l2
+from ksfd_amd.config import ProblemConfig
+from ksfd_amd.layout import cijk_to_soa, cijk_to_petsc, cijk_to_hdf5, PETSC, SOA, HDF5
+from ksfd_amd import lib as klib
+from oracle import ko
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12      # rel-L2 fp64; rounding-order differences only (oracle itself is within 1e-14 of the reference)
+
+
+@pytest.mark.parametrize('fused', [1, 0])
+@pytest.mark.parametrize('name', golden_cases('op_'))
+def test_operators_vs_reference_golden(name, fused):
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    k = klib.KSFDHip(cfg)
+    k.set_tuning(use_fused=fused, yseg=8)
+    u = cijk_to_soa(z['u'])
+    assert rel_l2(k.rhs(u), cijk_to_soa(z['rhs'])) < TOL
+    assert rel_l2(k.velocity(u), cijk_to_soa(z['vel'])) < TOL
+    assert rel_l2(k.jvp(cijk_to_soa(z['v']), u), cijk_to_soa(z['Jv'])) < TOL
+    # groom-active input: negatives, sub-floor values, NaNs (KSFD/ksfdsym.py:888-900)
+    ug = cijk_to_soa(z['ug'])
+    r = k.rhs(ug)
+    assert np.isfinite(r).all()
+    assert rel_l2(r, cijk_to_soa(z['rhs_g'])) < TOL
+    assert rel_l2(k.velocity(ug), cijk_to_soa(z['vel_g'])) < TOL
+    k.close()
+
+
+@pytest.mark.parametrize('name', ['op_2d_n2_aniso', 'op_3d_n1', 'op_1d_n1'])
+def test_layouts_roundtrip_and_petsc_layout_rhs(name):
+    """the reference's Vec is dof-fastest (KSFD/ksfdgrid.py:9-58); HDF5 datasets are (c,x,y,z) C order"""
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    k = klib.KSFDHip(cfg)
+    u = z['u']
+    k.set_state(cijk_to_petsc(u), PETSC)
+    assert np.array_equal(k.get_state(SOA), cijk_to_soa(u))
+    assert np.array_equal(k.get_state(HDF5), cijk_to_hdf5(u))
+    assert np.array_equal(k.get_state(PETSC), cijk_to_petsc(u))
+    k.set_state(cijk_to_hdf5(u), HDF5)
+    assert np.array_equal(k.get_state(SOA), cijk_to_soa(u))
+    assert rel_l2(k.rhs(cijk_to_petsc(u), layout=PETSC), cijk_to_petsc(z['rhs'])) < TOL
+    k.close()
+
+
+@pytest.mark.parametrize('shape,nlig', [((64, 48), 1), ((250, 36), 2), ((130, 20), 3), ((16, 16, 12), 2), ((37, 21), 1), ((96,), 1)])
+def test_operators_vs_oracle_seeded(shape, nlig):
+    """sizes that exercise several wave strips / row segments, odd extents (generic path), 3 ligands"""
+    dim = len(shape)
+    if nlig <= 2:
+        cfg = ProblemConfig.standard(dim, shape, L=[0.3 * (a + 1) for a in range(dim)], nlig=nlig)
+    else:
+        cfg = ProblemConfig(dim=dim, n=shape, L=(1.0, 0.7), lig_group=[0, 1, 0], lig_w=[1.0, 1.0, 0.5],
+                            lig_s=[0.01, 0.001, 0.02], lig_gamma=[0.01, 0.001, 0.03], lig_D=[1e-6, 1e-5, 2e-6],
+                            grp_alpha=[1500.0, 1500.0], grp_beta=[5.56e-4, -5.56e-4])
+    rng = np.random.default_rng(5)
+    N = int(np.prod(shape))
+    u = 9000 + 900 * rng.standard_normal(cfg.F * N)
+    v = rng.standard_normal(cfg.F * N)
+    o = ko.Oracle(cfg)
+    k = klib.KSFDHip(cfg)
+    for yseg in (32, 5):
+        k.set_tuning(use_fused=1, yseg=yseg)
+        assert rel_l2(k.rhs(u), o.rhs(u)) < TOL
+        assert rel_l2(k.jvp(v, u), o.jvp(u, v)) < TOL
+    src = [rng.standard_normal(N) for _ in range(cfg.F)]
+    for c in range(cfg.F):
+        k.set_source(c, src[c])
+    assert rel_l2(k.rhs(u), o.rhs(u, src)) < TOL
+    vmax_o, hcfl = o.cfl(u)
+    k.set_state(u)
+    assert np.allclose(k.velocity_max()[:dim], vmax_o[:dim], rtol=1e-11)
+    k.close()
+
+
+def test_outer_loop_helpers():
+    cfg = ProblemConfig.standard(2, (32, 24))
+    rng = np.random.default_rng(3)
+    N = 32 * 24
+    u = 9000 + 900 * rng.standard_normal(2 * N)
+    u[5] = np.nan
+    u[7] = -3.0
+    u[N + 9] = 1e-12
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    k.groom()
+    g = k.get_state()
+    assert np.array_equal(g, ko.Oracle(cfg).groom(u))
+    assert abs(k.count_worms() - g[:N].sum()) <= 1e-9 * g[:N].sum()
+    k.scale_rho(0.5)
+    f = np.exp(0.1 * rng.standard_normal(N))
+    k.mul_rho(f)
+    g2 = k.get_state()
+    assert np.allclose(g2[:N], g[:N] * 0.5 * f, rtol=1e-15)
+    assert np.array_equal(g2[N:], g[N:])
+    k.close()
