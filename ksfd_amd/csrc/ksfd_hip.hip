@@ -660,8 +660,8 @@ extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
 
 // ------------------------------------------------------------------------------------------------
 // matrix-free GMRES(m) for (shift I - J(u)) x = b, x0 = 0  -- replaces -ksp_type preonly -pc_type lu
-// (options84:58-60).  Classical Gram-Schmidt with one fused multi-dot per pass; a second pass
-// (DGKS-style refinement) only when the Pythagorean norm estimate has lost > 6 digits.
+// (options84:58-60).  Classical Gram-Schmidt applied twice (CGS2), one fused multi-dot + one fused
+// update kernel per pass; the new vector's norm comes from the second pass by Pythagoras.
 // ------------------------------------------------------------------------------------------------
 struct LinStats { int its; double rel; };
 
@@ -709,30 +709,20 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
             if ((rc = halo(h, vj)) || (rc = op_jvp(h, ustate, vj, 1, shift, w))) return rc;
             const int k = j + 1;
+            // CGS2: two classical Gram-Schmidt passes, each = one fused multi-dot + one fused update.
+            // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
             if ((rc = op_multidot(h, w, V, k))) return rc;
             for (int i = 0; i < k; i++) hcol[i] = h->hres[i];
-            double ww = h->hres[k], s2 = 0.0;
-            for (int i = 0; i < k; i++) s2 += hcol[i] * hcol[i];
-            double hn2 = ww - s2;
-            if (!(ww == ww)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
-            if (hn2 < 1e-6 * ww) {
-                // refinement pass: subtract, re-project, accumulate
-                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
-                if ((rc = op_multidot(h, w, V, k))) return rc;
-                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; }
-                ww = h->hres[k];
-                s2 = 0.0;
-                for (int i = 0; i < k; i++) s2 += d[i] * d[i];
-                hn2 = ww - s2;
-                if (hn2 < 0.0) hn2 = 0.0;
-                const double hn = sqrt(hn2);
-                if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
-                hcol[k] = hn;
-            } else {
-                const double hn = sqrt(hn2);
-                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0 / hn))) return rc;
-                hcol[k] = hn;
-            }
+            if (!(h->hres[k] == h->hres[k])) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+            if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
+            if ((rc = op_multidot(h, w, V, k))) return rc;
+            double s2 = 0.0;
+            for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
+            double hn2 = h->hres[k] - s2;              // ||w''||^2 by Pythagoras; d is O(eps) so this is accurate
+            if (hn2 < 0.0) hn2 = 0.0;
+            const double hn = sqrt(hn2);
+            if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
+            hcol[k] = hn;
             double *Hc = &H[(size_t)(m + 1) * j];
             for (int i = 0; i <= k; i++) Hc[i] = hcol[i];
             for (int i = 0; i < j; i++) { double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1]; Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1]; Hc[i] = t; }

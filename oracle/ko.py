@@ -52,6 +52,7 @@ def lib():
         _LIB.ko_tableau_get.argtypes = [dp] * 5
         _LIB.ko_rosw_step.argtypes = [cp, dp, C.c_double, C.POINTER(dp), C.c_double, C.c_double, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, dp, C.POINTER(C.c_int)]
+        _LIB.ko_set_threads.argtypes = [C.c_int]
         _LIB.ko_random_function.argtypes = [cp, C.POINTER(C.c_int64), dp, dp]
     return _LIB
 
@@ -154,6 +155,11 @@ class Oracle:
         out = np.empty(self.N)
         lib().ko_random_function(C.byref(self.k), ncs, _dp(z), _dp(out))
         return out
+
+
+def set_threads(n):
+    """OpenMP threads for the operator loops (cpu_baseline leg); default 1."""
+    lib().ko_set_threads(int(n))
 
 
 def wrms(unew, err, atol, rtol):

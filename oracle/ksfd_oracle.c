@@ -28,6 +28,10 @@
 
 #define KO_MAXF 8
 
+/* OpenMP is used only by the cpu_baseline timing leg; default is one thread (tests). */
+static int ko_threads = 1;
+void ko_set_threads(int n) { ko_threads = n < 1 ? 1 : n; }
+
 typedef struct ko_config {
     int32_t dim, nlig, ngroups, cap_kind;      /* cap_kind: 0 tophat, 1 witch (ksfdsoln.py:150-157) */
     int64_t n[3];
@@ -92,7 +96,7 @@ static void ko_G_point(const ko_config *c, double rho, const double *U, double *
 void ko_G(const ko_config *c, const double *ug, double *G)
 {
     int64_t N = ko_npts(c);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(ko_threads) if (ko_threads > 1)
     for (int64_t p = 0; p < N; p++) {
         double U[KO_MAXF];
         for (int l = 0; l < c->nlig; l++) U[l] = ug[(int64_t)(l + 1) * N + p];
@@ -134,7 +138,7 @@ int ko_rhs(const ko_config *c, const double *u, const double *const *src, double
     memcpy(ug, u, sizeof(double) * N * F);
     ko_groom(c, ug);
     ko_G(c, ug, G);
-#pragma omp parallel for schedule(static) collapse(2)
+#pragma omp parallel for schedule(static) collapse(2) num_threads(ko_threads) if (ko_threads > 1)
     for (int64_t k = 0; k < nz; k++)
         for (int64_t j = 0; j < ny; j++)
             for (int64_t i = 0; i < nx; i++) {
@@ -177,7 +181,7 @@ int ko_jvp(const ko_config *c, const double *u, const double *v, double *out)
     double *G = ug + (int64_t)F * N, *dG = G + N;
     memcpy(ug, u, sizeof(double) * N * F);
     ko_groom(c, ug);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(ko_threads) if (ko_threads > 1)
     for (int64_t p = 0; p < N; p++) {
         double U[KO_MAXF], GU[KO_MAXF], Gr;
         for (int l = 0; l < c->nlig; l++) U[l] = ug[(int64_t)(l + 1) * N + p];
@@ -186,7 +190,7 @@ int ko_jvp(const ko_config *c, const double *u, const double *v, double *out)
         for (int l = 0; l < c->nlig; l++) d += GU[l] * v[(int64_t)(l + 1) * N + p];
         dG[p] = d;
     }
-#pragma omp parallel for schedule(static) collapse(2)
+#pragma omp parallel for schedule(static) collapse(2) num_threads(ko_threads) if (ko_threads > 1)
     for (int64_t k = 0; k < nz; k++)
         for (int64_t j = 0; j < ny; j++)
             for (int64_t i = 0; i < nx; i++) {

@@ -33,3 +33,56 @@ def test_oracle_groom_active(name):
     assert np.isfinite(r).all()
     assert rel_l2(r, cijk_to_soa(z['rhs_g'])) < OP_TOL
     assert rel_l2(o.velocity(ug), cijk_to_soa(z['vel_g'])) < OP_TOL
+
+
+STEP_TOL = 1e-11
+
+
+@pytest.mark.parametrize('name', [n for n in golden_cases('step_') if 'manufactured' not in n])
+def test_oracle_step_vs_reference_lu_golden(name):
+    """oracle RA34PW2 (dense LU and GMRES) vs golden = reference operators + sparse LU + same tableau"""
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    o = ko.Oracle(cfg)
+    u = cijk_to_soa(z['u0'])
+    h, atol, rtol = float(z['h']), float(z['atol']), float(z['rtol'])
+    un, err, wr, _ = o.rosw_step(u, h, atol, rtol, solver='lu')
+    assert rel_l2(un, cijk_to_soa(z['u1'])) < STEP_TOL
+    assert rel_l2(err, cijk_to_soa(z['err1'])) < 1e-7
+    assert abs(wr - z['wrms'][0]) <= 1e-7 * z['wrms'][0]
+    ug, errg, wrg, its = o.rosw_step(u, h, atol, rtol, solver='gmres', ksp_rtol=1e-13)
+    assert rel_l2(ug, un) < STEP_TOL and its > 0
+    for s in range(1, int(z['nsteps'])):
+        un, err, wr, _ = o.rosw_step(un, h, atol, rtol, solver='lu')
+        assert abs(wr - z['wrms'][s]) <= 1e-6 * z['wrms'][s]
+    assert rel_l2(un, cijk_to_soa(z['uN'])) < STEP_TOL
+
+
+def test_oracle_manufactured_known_answer():
+    z = load_golden('step_1d_manufactured')
+    cfg = ProblemConfig.from_golden(z)
+    o = ko.Oracle(cfg)
+    u = cijk_to_soa(z['u0'])
+    for s in range(int(z['nsteps'])):
+        src = [sv if np.any(sv) else None for i in range(4) for sv in z['src_v'][4 * s + i]]
+        u, err, wr, _ = o.rosw_step(u, float(z['h']), float(z['atol']), float(z['rtol']), solver='lu', src_stage=src)
+    assert rel_l2(u, cijk_to_soa(z['uN'])) < STEP_TOL
+    assert np.abs(u - cijk_to_soa(z['exactN'])).max() < 2e-6
+
+
+def test_tableau_order_conditions():
+    """the RA34PW2 coefficients satisfy the order-3 / embedded order-2 conditions"""
+    At, Gi, bt, b2t, asum = ko.tableau()
+    G = np.linalg.inv(Gi)
+    A = At @ G
+    b, b2 = bt @ G, b2t @ G
+    gam = G[0, 0]
+    beta = (A + G).sum(axis=1)
+    alpha = A.sum(axis=1)
+    assert abs(b.sum() - 1) < 1e-14 and abs(b2.sum() - 1) < 1e-14
+    assert abs(b @ beta - 0.5) < 1e-14
+    assert abs(b @ alpha ** 2 - 1 / 3) < 1e-14
+    assert abs(b @ (A + G) @ beta - 1 / 6) < 1e-14
+    assert abs(b2 @ beta - 0.5) < 1e-14
+    assert np.allclose((A + G)[3], b)          # stiffly accurate
+    assert np.allclose(asum, alpha) and abs(gam - 4.3586652150845900e-01) < 1e-16
