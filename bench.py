@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-point-updates/s of the implicit Keller-Segel step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one implicit time step (KSFDTS.solve loop body, KSFD/ksfdts.py:207-228: groom -> 4-stage
+ROSW RA34PW2 step with matrix-free GMRES -> CFL velocity check) of the BASELINE.json headline config:
+2-D 4096^2, one ligand, fp64, synthetic random-perturbation initial data, state resident
+in HBM.  The SAME global grid is slab-decomposed over the N GPUs (strong scaling).
+
+One JSON line on rank 0, with `roofline` for the dominant kernel (algorithmic bytes per launch / HIP-event
+time per launch measured on the library's compute stream during the timed region) and `cpu_baseline`
+(the oracle's restatement of the same step, timed on the host cores on a bounded sub-grid sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_problem(n, nlig, spacing_ref=4.0 / 1536):
+    """options84-style physics (options84:20-46) on an n x n grid with the reference run's spacing
+    (width = 4*(n/1536))."""
+    from ksfd_amd.config import ProblemConfig
+    L = n * spacing_ref
+    return ProblemConfig.standard(2, (n, n), L=(L, L), nlig=nlig)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--n', type=int, default=4096)
+    ap.add_argument('--nlig', type=int, default=1)
+    ap.add_argument('--dt', type=float, default=0.05, help='first trial step (the controller adapts from here)')
+    ap.add_argument('--fixed-h', type=float, default=0.0, help='>0: -ts_adapt_type none with this step')
+    ap.add_argument('--ksp-rtol', type=float, default=1e-8)
+    ap.add_argument('--transport', default='auto', choices=['auto', 'rccl', 'host'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-n', type=int, default=512)
+    ap.add_argument('--yseg', type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ksfd_amd import lib as klib
+    from ksfd_amd.dist import open_handle, local_slab
+    from ksfd_amd.initial import start_values
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run' % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    host_group = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        host_group = dist.new_group(backend='gloo')
+    dev = local_rank if world > 1 else 0
+
+    cfg = build_problem(args.n, args.nlig)
+    u0 = start_values(cfg)                                  # global SoA state (identical on every rank)
+    ks, keep = open_handle(cfg, rank, world, dev, transport=args.transport, group=None, host_group=host_group)
+    if args.yseg:
+        ks.set_tuning(yseg=args.yseg)
+    ks.set_state(local_slab(u0, cfg, rank, world) if world > 1 else u0)
+    del u0
+
+    if args.fixed_h > 0:
+        opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=args.ksp_rtol)
+        h = args.fixed_h
+    else:
+        opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=args.ksp_rtol)   # options84:18-19
+        h = args.dt
+    t = 0.0
+    spacing = cfg.spacing
+
+    def one_step(t, h):
+        t, h, st, rc = ks.step(t, h, opts)                   # groom + ROSW/GMRES step (+ rejections)
+        vmax = ks.velocity_max()                              # CFL_check, KSFD/ksfdts.py:287-319
+        cfl = min(s * 2 / v if v > 0 else float('inf') for s, v in zip(spacing, vmax[:cfg.dim]))
+        return t, h, st, cfl
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ks.synchronize()
+
+    for _ in range(args.warmup):
+        t, h, st, cfl = one_step(t, h)
+    ks.set_profiling(True)
+    ks.profile(reset=True)
+    barrier()
+    t_start = time.perf_counter()
+    its, rej, hs, nbytes = 0, 0, [], 0.0
+    for _ in range(args.steps):
+        t, h, st, cfl = one_step(t, h)
+        its += st.linear_its
+        rej += st.rejections
+        hs.append(st.h_used)
+        nbytes += st.bytes
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    prof = ks.profile()
+    ks.set_profiling(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        N = cfg.N
+        value = N * args.steps / elapsed
+        # dominant kernel = largest share of device time in the timed region
+        dom = max(prof, key=lambda k: prof[k]['ms'])
+        d = prof[dom]
+        per_launch_bytes = d['bytes'] / max(d['launches'], 1)
+        per_launch_ms = d['ms'] / max(d['launches'], 1)
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        kern = {k: dict(ms=round(v['ms'], 3), launches=int(v['launches']),
+                        GBs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
+                for k, v in prof.items() if v['launches']}
+        out = {
+            'metric': 'grid-point-updates/sec (implicit step)', 'value': value, 'unit': 'grid-point-updates/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '2D %dx%d %d-ligand Keller-Segel, ROSW RA34PW2 + matrix-free GMRES(30,CGS2), '
+                                   'options84 spacing/physics, %s' % (args.n, args.n, args.nlig,
+                                                                      'fixed h=%g' % args.fixed_h if args.fixed_h > 0 else
+                                                                      'TSAdaptBasic rtol=1e-6 atol=0.01 from dt=%g' % args.dt),
+                       'grid': [args.n, args.n], 'fields': cfg.F, 'ksp_rtol': args.ksp_rtol,
+                       'h_mean': float(np.mean(hs)), 'gmres_its_per_step': its / args.steps, 'rejections': rej,
+                       't_end': t, 'parallelism': 'slab%d' % world},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'bytes_per_launch': per_launch_bytes, 'ms_per_launch': per_launch_ms,
+                         'step_algorithmic_GBs': nbytes / elapsed / 1e9,
+                         'step_frac_of_peak': nbytes / elapsed / 1e9 / HBM_PEAK_GBS},
+            'kernels': kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, float(np.mean(hs)))
+        print(json.dumps(out), flush=True)
+    ks.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, h):
+    """The oracle's restatement of the same step (kind 'port'), OpenMP over the host cores this process may
+    use, on a bounded sample: ONE step at the GPU run's mean h on an m x m sub-grid with the same spacing,
+    physics and initial-data statistics."""
+    from ksfd_amd.initial import start_values
+    from oracle import ko
+    m = args.cpu_sample_n
+    cfg = build_problem(m, args.nlig)
+    u = start_values(cfg)
+    cores = len(os.sched_getaffinity(0))
+    ko.set_threads(cores)
+    o = ko.Oracle(cfg)
+    t0 = time.perf_counter()
+    un, err, wr, its = o.rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=args.ksp_rtol, restart=30, maxit=2000)
+    dt = time.perf_counter() - t0
+    ko.set_threads(1)
+    return {'value': cfg.N / dt, 'unit': 'grid-point-updates/s', 'cores': cores, 'kind': 'port',
+            'sample': 'one ROSW+GMRES(30,CGS2) step at h=%.4g on a %dx%d sub-grid (same spacing/physics/IC '
+                      'statistics), %d GMRES its, %.1f s' % (h, m, m, its, dt)}
+
+
+if __name__ == '__main__':
+    main()

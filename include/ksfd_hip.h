@@ -118,6 +118,9 @@ const char *ksfd_kernel_class_name(int32_t cls);
 
 typedef struct ksfd_handle ksfd_handle;
 
+/* 128-byte ncclUniqueId from the same librccl the library resolves (rank 0 calls, the launcher broadcasts it) */
+int ksfd_rccl_unique_id(void *out128);
+
 /* -- lifetime.  dist == NULL: single GPU (device 0 or HIP_VISIBLE_DEVICES), in-kernel periodic wrap. */
 int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_handle **out);
 void ksfd_destroy(ksfd_handle *h);

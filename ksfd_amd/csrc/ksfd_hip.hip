@@ -486,6 +486,21 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     return KSFD_OK;
 }
 
+extern "C" int ksfd_rccl_unique_id(void *out128)
+{
+    if (!out128) return KSFD_EINVAL;
+    std::string err;
+    RcclApi api;
+    if (!api.load(err)) return fail(nullptr, KSFD_ECOMM, "%s", err.c_str());
+    auto getid = (decltype(&ncclGetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    if (!getid) return fail(nullptr, KSFD_ECOMM, "librccl lacks ncclGetUniqueId");
+    ncclUniqueId id;
+    ncclResult_t r = getid(&id);
+    if (r != ncclSuccess) return fail(nullptr, KSFD_ECOMM, "ncclGetUniqueId: %s", api.GetErrorString(r));
+    memcpy(out128, &id, sizeof id);
+    return KSFD_OK;
+}
+
 extern "C" int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg)
 {
     if (!h || !cfg) return KSFD_EINVAL;

@@ -1,0 +1,157 @@
+"""Slab decomposition + halo transports for more than one GPU (one process per GPU).
+
+The reference distributes the grid with a PETSc DMDA (KSFD/ksfdgrid.py:388-411) and exchanges width-2
+STAR ghosts on every RHS / Jacobian / velocity evaluation (KSFD/ksfdsym.py:704,787,920,1203).  Here the
+grid is cut into slabs along the slowest spatial axis; rank r owns [r*n/P, (r+1)*n/P) and its ring
+neighbours are (r-1) mod P and (r+1) mod P (periodic box).
+
+Two transports feed include/ksfd_hip.h:ksfd_dist:
+  1  RCCL inside the library (ncclSend/ncclRecv/ncclAllReduce on the compute stream, over xGMI);
+     this module only broadcasts the ncclUniqueId through torch.distributed.
+  2  host callbacks: the exchange runs here through torch.distributed on the pinned staging buffers
+     the library hands over (works with gloo, with mpi4py-style launchers, and with several ranks
+     sharing one GPU).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as klib
+
+
+def slab_range(n_slow, rank, size):
+    """Owned slow-axis interval of `rank` (must agree with ksfd_create)."""
+    if n_slow % size or n_slow // size < 4:
+        raise ValueError('slab axis extent %d must be divisible by %d ranks with >= 4 units each' % (n_slow, size))
+    per = n_slow // size
+    return rank * per, (rank + 1) * per
+
+
+def neighbours(rank, size):
+    return (rank - 1) % size, (rank + 1) % size
+
+
+def local_slab(global_soa, cfg, rank, size):
+    """Cut this rank's slab out of a flat global SoA state (x fastest)."""
+    F = cfg.F
+    lo, hi = slab_range(cfg.n[cfg.dim - 1], rank, size)
+    shape = (F,) + tuple(reversed(cfg.n[:cfg.dim]))          # (F, [nz,] ny, nx) C order == x fastest
+    a = np.asarray(global_soa).reshape(shape)
+    return np.ascontiguousarray(a[:, lo:hi]).reshape(-1)
+
+
+def gather_slabs(local, cfg, group=None):
+    """all_gather the local SoA slabs back into the global SoA state (for checks and output)."""
+    import torch
+    import torch.distributed as dist
+    size = dist.get_world_size(group)
+    F = cfg.F
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    outs = [torch.empty_like(t) for _ in range(size)]
+    dist.all_gather(outs, t, group=group)
+    shp = list((F,) + tuple(reversed(cfg.n[:cfg.dim])))
+    shp[1] //= size
+    parts = [o.numpy().reshape(shp) for o in outs]
+    return np.concatenate(parts, axis=1).reshape(-1)
+
+
+class HostRing:
+    """torch.distributed implementation of the transport-2 callbacks (any backend that moves CPU tensors)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.lo, self.hi = neighbours(self.rank, self.size)
+        self.errors = []
+        self._ex = klib.EXCHANGE_FN(self._exchange)
+        self._ar = klib.ALLREDUCE_FN(self._allreduce)
+
+    def _view(self, ptr, n):
+        return self.torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(n,)))
+
+    def exchange_arrays(self, slo, shi, rlo, rhi):
+        """send_lo -> lower neighbour's recv_hi ; send_hi -> upper neighbour's recv_lo (numpy float64 arrays)."""
+        d, g = self.dist, self.group
+        t = self.torch.from_numpy
+        to_global = (lambda r: d.get_global_rank(g, r)) if g is not None else (lambda r: r)
+        reqs = [d.isend(t(slo), to_global(self.lo), group=g, tag=0),
+                d.isend(t(shi), to_global(self.hi), group=g, tag=1),
+                d.irecv(t(rhi), to_global(self.hi), group=g, tag=0),
+                d.irecv(t(rlo), to_global(self.lo), group=g, tag=1)]
+        for r in reqs:
+            r.wait()
+
+    def _exchange(self, ctx, slo, shi, rlo, rhi, count):
+        try:
+            n = int(count)
+            self.exchange_arrays(*(np.ctypeslib.as_array(p, shape=(n,)) for p in (slo, shi, rlo, rhi)))
+            return 0
+        except Exception as e:            # never let an exception cross the C boundary
+            self.errors.append(repr(e))
+            return 1
+
+    def _allreduce(self, ctx, buf, count, op):
+        try:
+            v = self._view(buf, int(count))
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX if op else self.dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception as e:
+            self.errors.append(repr(e))
+            return 1
+
+    def cdist(self, device=0):
+        d = klib.CDist()
+        d.rank, d.size, d.transport, d.device = self.rank, self.size, 2, device
+        d.nccl_id = None
+        d.exchange, d.allreduce, d.ctx = self._ex, self._ar, None
+        return d
+
+
+def rccl_cdist(rank, size, device, group=None):
+    """transport 1: rank 0 creates the ncclUniqueId, torch.distributed broadcasts it."""
+    import torch.distributed as dist
+    box = [klib.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    buf = C.create_string_buffer(box[0], 128)
+    d = klib.CDist()
+    d.rank, d.size, d.transport, d.device = rank, size, 1, device
+    d.nccl_id = C.cast(buf, C.c_void_p)
+    d._keepalive = buf
+    return d
+
+
+def open_handle(cfg, rank, size, device, transport='auto', group=None, host_group=None):
+    """Create this rank's KSFDHip.  transport: 'rccl', 'host' or 'auto' (RCCL, falling back to the host
+    callbacks when RCCL cannot be initialised on every rank; the decision is agreed across ranks).
+    Returns (KSFDHip, keepalive)."""
+    import torch
+    import torch.distributed as dist
+    if size == 1:
+        return klib.KSFDHip(cfg), None
+    g = host_group if host_group is not None else group
+    if transport in ('auto', 'rccl'):
+        ok, ks, d, why = 1, None, None, ''
+        try:
+            d = rccl_cdist(rank, size, device, group)
+            ks = klib.KSFDHip(cfg, d)
+        except Exception as e:            # noqa: BLE001
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        if dist.get_backend(g) == 'nccl':
+            flag = flag.cuda(device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)
+        if int(flag.item()) == 1:
+            return ks, d
+        if ks is not None:
+            ks.close()
+        if transport == 'rccl':
+            raise RuntimeError('RCCL transport unavailable: ' + why)
+        if rank == 0:
+            print('[ksfd_amd.dist] RCCL transport unavailable (%s); using host-callback transport' % why, flush=True)
+    ring = HostRing(g)
+    ks = klib.KSFDHip(cfg, ring.cdist(device))
+    ks._ring = ring
+    return ks, ring

@@ -62,7 +62,7 @@ _lib = None
 
 # every symbol include/ksfd_hip.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = [
-    'ksfd_kernel_class_name', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
+    'ksfd_kernel_class_name', 'ksfd_rccl_unique_id', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
     'ksfd_local_range', 'ksfd_local_size', 'ksfd_set_state', 'ksfd_get_state', 'ksfd_device_state',
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
     'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho',
@@ -83,6 +83,7 @@ def load():
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     L.ksfd_kernel_class_name.restype = C.c_char_p
     L.ksfd_kernel_class_name.argtypes = [C.c_int32]
+    L.ksfd_rccl_unique_id.argtypes = [vp]
     L.ksfd_create.argtypes = [C.POINTER(CConfig), C.POINTER(CDist), C.POINTER(vp)]
     L.ksfd_destroy.argtypes = [vp]
     L.ksfd_destroy.restype = None
@@ -124,6 +125,15 @@ def load():
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId (call on rank 0, broadcast to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    rc = load().ksfd_rccl_unique_id(C.cast(buf, C.c_void_p))
+    if rc:
+        raise KSFDError(rc, (load().ksfd_last_error(None) or b'').decode())
+    return bytes(buf.raw)
 
 
 def default_step_opts(**kw):

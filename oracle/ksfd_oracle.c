@@ -441,8 +441,12 @@ static int ko_gmres(const ko_op *op, int64_t n, const double *b, double *x, doub
             for (int i = 0; i <= j; i++) h[i] = 0.0;
             for (int pass = 0; pass < 2; pass++) {
                 double d[64];
-                for (int i = 0; i <= j; i++) { const double *vi = V + n * i; double s = 0.0; for (int64_t q = 0; q < n; q++) s += vi[q] * vn[q]; d[i] = s; }
-                for (int i = 0; i <= j; i++) { const double *vi = V + n * i; double s = d[i]; for (int64_t q = 0; q < n; q++) vn[q] -= s * vi[q]; h[i] += s; }
+                for (int i = 0; i <= j; i++) { const double *vi = V + n * i; double s = 0.0;
+_Pragma("omp parallel for reduction(+:s) schedule(static) num_threads(ko_threads) if (ko_threads > 1)")
+                    for (int64_t q = 0; q < n; q++) s += vi[q] * vn[q]; d[i] = s; }
+                for (int i = 0; i <= j; i++) { const double *vi = V + n * i; double s = d[i];
+_Pragma("omp parallel for schedule(static) num_threads(ko_threads) if (ko_threads > 1)")
+                    for (int64_t q = 0; q < n; q++) vn[q] -= s * vi[q]; h[i] += s; }
             }
             double hn = 0.0;
             for (int64_t q = 0; q < n; q++) hn += vn[q] * vn[q];
