@@ -163,6 +163,19 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Host cores this process may really use: cgroup quota if there is one, else the affinity mask,
+    capped at 16 (the GPU box's CPU share per GPU; its affinity mask shows all 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline(args, h):
     """The oracle's restatement of the same step (kind 'port'), OpenMP over the host cores this process may
     use, on a bounded sample: ONE step at the GPU run's mean h on an m x m sub-grid with the same spacing,
@@ -172,7 +185,7 @@ def cpu_baseline(args, h):
     m = args.cpu_sample_n
     cfg = build_problem(m, args.nlig)
     u = start_values(cfg)
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     ko.set_threads(cores)
     o = ko.Oracle(cfg)
     t0 = time.perf_counter()

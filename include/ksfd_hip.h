@@ -92,7 +92,7 @@ typedef struct ksfd_step_opts {
     double ksp_rtol, ksp_atol;  /* GMRES: stop at ||r|| <= max(ksp_rtol*||b||, ksp_atol) */
     int32_t ksp_restart, ksp_max_it;
     int32_t pc_type;            /* 0 none (round 1) */
-    int32_t reserved;
+    int32_t reserved;           /* 0: CGS2 with algebraic second projection (default); 1: classic two-pass CGS2 */
 } ksfd_step_opts;
 
 typedef struct ksfd_step_stats {
@@ -170,7 +170,8 @@ int ksfd_synchronize(ksfd_handle *h);
 /* raw kernel benchmark used by bench.py/profiles: run `reps` launches of one kernel class on the state,
  * timed with HIP events on the compute stream; returns average ms per launch. */
 int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms, double *bytes_per_launch);
-int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg);
+/* use_fused: bit0 fused 2-D kernels, bit1 set = recompute (non-frozen) Jacobian action; yseg_*: rows per wave segment; <=0 keeps */
+int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,8 @@ struct ksfd_handle {
     double *u = nullptr, *usave = nullptr, *Z = nullptr, *bvec = nullptr, *Y = nullptr, *V = nullptr;
     double *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *errv = nullptr;
     double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes
+    double *coef = nullptr;                 // frozen-Jacobian coefficient planes [rho, G, G_rho, G_U..]
+    bool use_frozen = true;
     double *flat = nullptr;                 // staging for host layouts: max(F,dim)*nloc
     double *src[4][KSFD_MAXL + 1];          // dense source planes per stage (lazy)
     double *part = nullptr;                 // block partials
@@ -57,7 +59,8 @@ struct ksfd_handle {
 
     // tuning
     int use_fused = 1;
-    int yseg = 32;
+    int yseg = 32;        // rows per wave segment, RHS kernel (measured best at 4096^2)
+    int yseg_jvp = 16;    // same for the Jacobian-action kernels
 
     // profile
     bool profiling = false;
@@ -237,11 +240,11 @@ static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
     default: { constexpr int NL = 6; CALL; } break;                                                \
     }
 
-static KStrips make_strips(const ksfd_handle *h)
+static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
 {
     KStrips S;
     S.nstrips = (int)((h->G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-    S.yseg = h->yseg;
+    S.yseg = jvp ? h->yseg_jvp : h->yseg;
     S.nseg = (int)((h->G.sloc + S.yseg - 1) / S.yseg);
     long long waves = (long long)S.nstrips * S.nseg;
     long long nb = (waves + 3) / 4;
@@ -285,7 +288,7 @@ static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, do
 {
     const KGeom &G = h->G;
     if (fused_ok(h)) {
-        KStrips K = make_strips(h);
+        KStrips K = make_strips(h, true);
         Scope sc(h, KC_JVP, vbytes(h, 3));
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, v, mode, shift, out));
     } else {
@@ -302,18 +305,58 @@ static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, do
     return KSFD_OK;
 }
 
+// Once per step: C = [rho, G, G_rho, G_U..] of the (ghost-filled) state u
+static int op_jcoef(ksfd_handle *h, const double *u)
+{
+    const KGeom &G = h->G;
+    int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    Scope sc(h, KC_GFIELD, 8.0 * (G.F + 3 + h->P.nlig) * (double)G.plane);
+    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef));
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// Jacobian action from the frozen coefficients (see stencil.hip.h, "Frozen-Jacobian path")
+static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift, double *out)
+{
+    const KGeom &G = h->G;
+    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F;
+    if (fused_ok(h)) {
+        KStrips K = make_strips(h, true);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
+        }
+        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
+        // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// VW = 2 when every plane/offset/length is even (all accesses 16-byte aligned double2)
+static inline bool vec2(const ksfd_handle *h) { return (h->G.nloc % 2 == 0) && (h->kv.off % 2 == 0) && (h->G.plane % 2 == 0); }
+static inline dim3 vgridw(const ksfd_handle *h, int vw) { return dim3((h->nblk_vec + vw - 1) / vw, h->G.F); }
+#define VW_DISPATCH(h, CALL) do { if (vec2(h)) { constexpr int VW = 2; CALL; } else { constexpr int VW = 1; CALL; } } while (0)
+
 static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const double *a, double *out)
 {
     KLin L;
     for (int t = 0; t < 6; t++) { L.x[t] = t < nt ? x[t] : nullptr; L.a[t] = t < nt ? a[t] : 0.0; }
     Scope sc(h, KC_LINCOMB, vbytes(h, nt + 1));
     switch (nt) {
-    case 1: hipLaunchKernelGGL((k_lincomb<1>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
-    case 2: hipLaunchKernelGGL((k_lincomb<2>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
-    case 3: hipLaunchKernelGGL((k_lincomb<3>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
-    case 4: hipLaunchKernelGGL((k_lincomb<4>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
-    case 5: hipLaunchKernelGGL((k_lincomb<5>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
-    default: hipLaunchKernelGGL((k_lincomb<6>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out); break;
+    case 1: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<1, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 2: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<2, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 3: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<3, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 4: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 5: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<5, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    default: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<6, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -322,16 +365,31 @@ static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const doub
 // d[0..k) = <w,V_i>, d[k] = <w,w>  -> h->hres
 static int op_multidot(ksfd_handle *h, const double *w, const double *V, int k)
 {
-    const int nb = h->nblk_vec;
+    const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
     {
         Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
-        if (k <= 4) hipLaunchKernelGGL((k_multidot<4>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
-        else if (k <= 8) hipLaunchKernelGGL((k_multidot<8>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
-        else if (k <= 16) hipLaunchKernelGGL((k_multidot<16>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
-        else hipLaunchKernelGGL((k_multidot<32>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part);
+        if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
     }
     HIPCHK(h, hipGetLastError());
     return reduce_rows(h, k + 1, nb, 0);
+}
+
+// d[0..k) = <w,V_i>, g[0..k) = <V_{k-1},V_i>, ww  -> h->hres[0..2k]
+static int op_multidot_gram(ksfd_handle *h, const double *w, const double *V, int k)
+{
+    const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
+    {
+        Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
+        if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+    }
+    HIPCHK(h, hipGetLastError());
+    return reduce_rows(h, 2 * k + 1, nb, 0);
 }
 
 static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const double *coef, double scale)
@@ -339,10 +397,10 @@ static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const
     KCoef C;
     for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
     Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
-    if (k <= 4) hipLaunchKernelGGL((k_gs_update<4>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
-    else if (k <= 8) hipLaunchKernelGGL((k_gs_update<8>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
-    else if (k <= 16) hipLaunchKernelGGL((k_gs_update<16>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
-    else hipLaunchKernelGGL((k_gs_update<32>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale);
+    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    else VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
 }
@@ -352,10 +410,10 @@ static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, cons
     KCoef C;
     for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
     Scope sc(h, KC_BASISAXPY, vbytes(h, k + 1 + (beta != 0.0)));
-    if (k <= 4) hipLaunchKernelGGL((k_basis_axpy<4>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
-    else if (k <= 8) hipLaunchKernelGGL((k_basis_axpy<8>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
-    else if (k <= 16) hipLaunchKernelGGL((k_basis_axpy<16>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
-    else hipLaunchKernelGGL((k_basis_axpy<32>), vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta);
+    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    else VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
 }
@@ -404,7 +462,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->st) hipStreamSynchronize(h->st);
-    double *bufs[] = { h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
+    double *bufs[] = { h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
     for (double *b : bufs) if (b) hipFree(b);
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
     if (h->hres) hipHostFree(h->hres);
@@ -457,7 +515,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     G.nloc = sloc * G.inner;
     h->kv.plane = G.plane; h->kv.off = (long long)G.ng * G.inner; h->kv.nloc = G.nloc; h->kv.nf = G.F;
     h->vlen = (int64_t)G.F * G.plane;
-    h->nblk_vec = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 1024);
+    h->nblk_vec = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
     build_tableau(h);
 
     h->restart_alloc = 30;
@@ -467,13 +525,13 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         hipMemsetAsync(*v, 0, sizeof(double) * (size_t)h->vlen, h->st);
     }
     if (alloc_d(h, &h->Y, 4 * h->vlen) || alloc_d(h, &h->V, (int64_t)(h->restart_alloc + 1) * h->vlen) ||
-        alloc_d(h, &h->Gb, G.plane) || alloc_d(h, &h->dGb, G.plane) ||
+        alloc_d(h, &h->Gb, G.plane) || alloc_d(h, &h->dGb, G.plane) || alloc_d(h, &h->coef, (int64_t)(3 + cfg->nlig) * G.plane) ||
         alloc_d(h, &h->flat, (int64_t)std::max(G.F, 3) * G.nloc) ||
-        alloc_d(h, &h->part, (int64_t)(KSFD_MAXDOT + 2) * 4096) || alloc_d(h, &h->dres, 64))
+        alloc_d(h, &h->part, (int64_t)(2 * KSFD_MAXDOT + 4) * 4096) || alloc_d(h, &h->dres, 128))
         CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
     hipMemsetAsync(h->Y, 0, sizeof(double) * (size_t)(4 * h->vlen), h->st);
     hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)((h->restart_alloc + 1) * h->vlen), h->st);
-    if (hipHostMalloc((void **)&h->hres, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
+    if (hipHostMalloc((void **)&h->hres, sizeof(double) * 128, hipHostMallocDefault) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
 
     if (h->size > 1) {
         std::string terr;
@@ -688,7 +746,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     const int64_t vs = h->vlen;
     double *V = h->V;
     int rc;
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2);
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2), Gm((size_t)(m + 1) * (m + 1), 0.0);
     if ((rc = op_multidot(h, b, V, 0))) return rc;
     const double bn = sqrt(h->hres[0]);
     ls->its = 0; ls->rel = 0.0;
@@ -705,7 +763,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         // V0 = r / beta
         if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
         else {
-            if ((rc = halo(h, x)) || (rc = op_jvp(h, ustate, x, 1, shift, V))) return rc;     // V0 = A x
+            if ((rc = halo(h, x)) || (rc = (h->use_frozen ? op_jvp_frozen(h, x, 1, shift, V) : op_jvp(h, ustate, x, 1, shift, V)))) return rc;     // V0 = A x
             const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
             if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;                                  // r = b - A x
             if ((rc = op_multidot(h, V, V, 0))) return rc;
@@ -722,22 +780,62 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         bool done = false;
         for (; j < m && total < maxit; j++) {
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
-            if ((rc = halo(h, vj)) || (rc = op_jvp(h, ustate, vj, 1, shift, w))) return rc;
+            if ((rc = halo(h, vj)) || (rc = (h->use_frozen ? op_jvp_frozen(h, vj, 1, shift, w) : op_jvp(h, ustate, vj, 1, shift, w)))) return rc;
             const int k = j + 1;
-            // CGS2: two classical Gram-Schmidt passes, each = one fused multi-dot + one fused update.
-            // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
-            if ((rc = op_multidot(h, w, V, k))) return rc;
-            for (int i = 0; i < k; i++) hcol[i] = h->hres[i];
-            if (!(h->hres[k] == h->hres[k])) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
-            if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
-            if ((rc = op_multidot(h, w, V, k))) return rc;
-            double s2 = 0.0;
-            for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
-            double hn2 = h->hres[k] - s2;              // ||w''||^2 by Pythagoras; d is O(eps) so this is accurate
-            if (hn2 < 0.0) hn2 = 0.0;
-            const double hn = sqrt(hn2);
-            if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
-            hcol[k] = hn;
+            if (o->reserved == 1) {
+                // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
+                // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
+                if ((rc = op_multidot(h, w, V, k))) return rc;
+                for (int i = 0; i < k; i++) hcol[i] = h->hres[i];
+                if (!(h->hres[k] == h->hres[k])) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
+                if ((rc = op_multidot(h, w, V, k))) return rc;
+                double s2 = 0.0;
+                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
+                double hn2 = h->hres[k] - s2;          // ||w''||^2 by Pythagoras; d is O(eps) so this is accurate
+                if (hn2 < 0.0) hn2 = 0.0;
+                const double hn = sqrt(hn2);
+                if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
+                hcol[k] = hn;
+            } else {
+                // CGS2 with the second projection done algebraically (halves the Gram-Schmidt traffic):
+                //   d = V^T w and the Gram row g = V^T v_j come from ONE pass over V; with G = V^T V,
+                //   the twice-projected coefficients are c = d + (I - G) d, and
+                //   ||w - V c||^2 = ww - 2 c.d + c.G c.   One fused update pass applies c and normalises.
+                if ((rc = op_multidot_gram(h, w, V, k))) return rc;
+                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; Gm[(size_t)i * (m + 1) + j] = Gm[(size_t)j * (m + 1) + i] = h->hres[k + i]; }
+                const double ww = h->hres[2 * k];
+                if (!(ww == ww)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+                for (int i = 0; i < k; i++) {
+                    double s = 0.0;
+                    for (int l = 0; l < k; l++) s += ((i == l ? 1.0 : 0.0) - Gm[(size_t)i * (m + 1) + l]) * d[l];
+                    hcol[i] = d[i] + s;
+                }
+                double cd = 0.0, cGc = 0.0;
+                for (int i = 0; i < k; i++) {
+                    cd += hcol[i] * d[i];
+                    double s = 0.0;
+                    for (int l = 0; l < k; l++) s += Gm[(size_t)i * (m + 1) + l] * hcol[l];
+                    cGc += hcol[i] * s;
+                }
+                double hn2 = ww - 2.0 * cd + cGc;
+                double hn;
+                if (hn2 > 1e-8 * ww) {
+                    hn = sqrt(hn2);
+                    if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0 / hn))) return rc;
+                } else {
+                    // heavy cancellation (||w|| >> ||w - Vc||): apply c, then measure and project once more
+                    if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
+                    if ((rc = op_multidot(h, w, V, k))) return rc;
+                    double s2 = 0.0;
+                    for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
+                    hn2 = h->hres[k] - s2;
+                    if (hn2 < 0.0) hn2 = 0.0;
+                    hn = sqrt(hn2);
+                    if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
+                }
+                hcol[k] = hn;
+            }
             double *Hc = &H[(size_t)(m + 1) * j];
             for (int i = 0; i <= k; i++) Hc[i] = hcol[i];
             for (int i = 0; i < j; i++) { double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1]; Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1]; Hc[i] = t; }
@@ -799,6 +897,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     if ((rc = ksfd_groom(h))) goto out;
     if ((rc = op_copy(h, h->usave, h->u))) goto out;
     if ((rc = halo(h, h->u))) goto out;
+    if (h->use_frozen && (rc = op_jcoef(h, h->u))) goto out;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
         for (int i = 0; i < 4 && !rc; i++) {
@@ -912,11 +1011,12 @@ extern "C" int ksfd_synchronize(ksfd_handle *h)
     HIPCHK(h, hipStreamSynchronize(h->st));
     return KSFD_OK;
 }
-extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg)
+extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, int32_t yseg_jvp)
 {
     if (!h) return KSFD_EINVAL;
-    if (use_fused >= 0) h->use_fused = use_fused;
+    if (use_fused >= 0) { h->use_fused = use_fused & 1; h->use_frozen = !(use_fused & 2); }
     if (yseg > 0) h->yseg = yseg;
+    if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;
     return KSFD_OK;
 }
 
@@ -939,10 +1039,10 @@ extern "C" int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, doub
         double coef[KSFD_MAXDOT] = { 0 };
         switch (cls) {
         case KC_RHS: r = op_rhs(h, h->u, -1, h->t3); break;
-        case KC_JVP: r = op_jvp(h, h->u, h->Y, 1, 1.0, h->t3); break;
+        case KC_JVP: r = h->use_frozen ? op_jvp_frozen(h, h->Y, 1, 1.0, h->t3) : op_jvp(h, h->u, h->Y, 1, 1.0, h->t3); break;
         case KC_MULTIDOT: {
             Scope sc(h, KC_MULTIDOT, vbytes(h, 9));
-            hipLaunchKernelGGL((k_multidot<8>), dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)h->t3, (const double *)h->V, h->vlen, 8, h->part);
+            VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<8, VW>), dim3(vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)h->t3, (const double *)h->V, h->vlen, 8, h->part));
         } break;
         case KC_GSUPDATE: r = op_gs_update(h, h->t3, h->V, 8, coef, 1.0); break;
         case KC_LINCOMB: { const double *xs[3] = { h->u, h->Y, h->Y + h->vlen }; double aa[3] = { 1.0, 0.5, 0.25 }; r = op_lincomb(h, 3, xs, aa, h->t3); } break;
@@ -952,6 +1052,7 @@ extern "C" int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, doub
         return r;
     };
     if ((rc = halo(h, h->u))) goto done;
+    if (h->use_frozen && cls == KC_JVP && (rc = op_jcoef(h, h->u))) goto done;
     for (int i = 0; i < 3 && !rc; i++) rc = one();
     if (rc) goto done;
     hipEventRecord(a, h->st);

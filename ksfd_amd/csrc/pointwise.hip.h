@@ -68,29 +68,53 @@ struct KVec {
     int nf;                       // number of field planes (F)
 };
 
+// All BLAS-1 kernels are templated on VW = doubles per lane per access (2 when the slab geometry is
+// even, so every access is a 16-byte double2: 1 KiB per wave instruction; else 1).
+template <int VW> struct KPack;
+template <> struct KPack<1> { typedef double T; };
+template <> struct KPack<2> { typedef double2 T; };
+__device__ __forceinline__ double kget(const double &v, int) { return v; }
+__device__ __forceinline__ double kget(const double2 &v, int e) { return e ? v.y : v.x; }
+__device__ __forceinline__ void kset(double &v, int, double x) { v = x; }
+__device__ __forceinline__ void kset(double2 &v, int e, double x) { if (e) v.y = x; else v.x = x; }
+template <int VW> __device__ __forceinline__ typename KPack<VW>::T kload(const double *p)
+{
+    return *reinterpret_cast<const typename KPack<VW>::T *>(p);
+}
+template <int VW> __device__ __forceinline__ void kstore(double *p, const typename KPack<VW>::T &v)
+{
+    *reinterpret_cast<typename KPack<VW>::T *>(p) = v;
+}
+
 // out = sum_t a[t] * x[t]   (NT <= 6 inputs; out may alias any x[t]).  Used for the ROSW stage
 // vectors (VecMAXPY/VecWAXPY in PETSc's TSStep_RosW) and the GMRES solution update.
 struct KLin {
     const double *x[6];
     double a[6];
 };
-template <int NT>
+template <int NT, int VW>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_lincomb(KVec g, KLin L, double *out)
 {
     const long long base = (long long)blockIdx.y * g.plane + g.off;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
-        double s = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
+        typename KPack<VW>::T s, xv;
 #pragma unroll
-        for (int t = 0; t < NT; t++) s += L.a[t] * L.x[t][base + p];
-        out[base + p] = s;
+        for (int e = 0; e < VW; e++) kset(s, e, 0.0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            xv = kload<VW>(L.x[t] + base + p);
+#pragma unroll
+            for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) + L.a[t] * kget(xv, e));
+        }
+        kstore<VW>(out + base + p, s);
     }
 }
 
 // Krylov dot products: d[i] = <w, V_i> for i < k, and d[k] = <w, w>, in ONE pass over w.
 // V_i = V + i*vstride.  Block partials go to part[i*nblk + b]; k_reduce_rows finishes them
 // in a fixed order (bitwise reproducible; no float atomics).
-template <int KMAX>
+template <int KMAX, int VW>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_multidot(KVec g, const double *__restrict__ w,
                                                          const double *__restrict__ V, long long vstride,
                                                          int k, double *__restrict__ part)
@@ -99,15 +123,20 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_multidot(KVec g, const double *_
     double acc[KMAX + 1];
 #pragma unroll
     for (int i = 0; i <= KMAX; i++) acc[i] = 0.0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long stride = (long long)gridDim.x * blockDim.x * VW;
     for (int c = 0; c < g.nf; c++) {
         const long long base = (long long)c * g.plane + g.off;
-        for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
-            const double wv = w[base + p];
+        for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
+            const typename KPack<VW>::T wv = kload<VW>(w + base + p);
 #pragma unroll
             for (int i = 0; i < KMAX; i++)
-                if (i < k) acc[i] += wv * V[(long long)i * vstride + base + p];
-            acc[KMAX] += wv * wv;
+                if (i < k) {
+                    const typename KPack<VW>::T vv = kload<VW>(V + (long long)i * vstride + base + p);
+#pragma unroll
+                    for (int e = 0; e < VW; e++) acc[i] += kget(wv, e) * kget(vv, e);
+                }
+#pragma unroll
+            for (int e = 0; e < VW; e++) acc[KMAX] += kget(wv, e) * kget(wv, e);
         }
     }
     const int lane = threadIdx.x & (KSFD_WAVE - 1), wv_ = threadIdx.x / KSFD_WAVE;
@@ -125,6 +154,62 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_multidot(KVec g, const double *_
             double s = 0.0;
             for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) s += red[q][i];
             int row = (i == KMAX) ? k : i;
+            part[(long long)row * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+// One-pass Gram-Schmidt data for GMRES with a lagged Gram row (see gmres() in ksfd_hip.hip):
+//   rows 0..k-1   : d[i] = <w, V_i>
+//   rows k..2k-1  : g[i] = <V_{k-1}, V_i>      (Gram row of the newest basis vector)
+//   row  2k       : <w, w>
+// Reads w and V_0..V_{k-1} exactly once.
+template <int KMAX, int VW>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_multidot_gram(KVec g, const double *__restrict__ w,
+                                                              const double *__restrict__ V, long long vstride,
+                                                              int k, double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE][2 * KMAX + 1];
+    double acc[2 * KMAX + 1];
+#pragma unroll
+    for (int i = 0; i <= 2 * KMAX; i++) acc[i] = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    for (int c = 0; c < g.nf; c++) {
+        const long long base = (long long)c * g.plane + g.off;
+        for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
+            const typename KPack<VW>::T wv = kload<VW>(w + base + p);
+            const typename KPack<VW>::T lv = kload<VW>(V + (long long)(k - 1) * vstride + base + p);
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k) {
+                    const typename KPack<VW>::T vv = (i == k - 1) ? lv : kload<VW>(V + (long long)i * vstride + base + p);
+#pragma unroll
+                    for (int e = 0; e < VW; e++) {
+                        acc[i] += kget(wv, e) * kget(vv, e);
+                        acc[KMAX + i] += kget(lv, e) * kget(vv, e);
+                    }
+                }
+#pragma unroll
+            for (int e = 0; e < VW; e++) acc[2 * KMAX] += kget(wv, e) * kget(wv, e);
+        }
+    }
+    const int lane = threadIdx.x & (KSFD_WAVE - 1), wv_ = threadIdx.x / KSFD_WAVE;
+#pragma unroll
+    for (int i = 0; i <= 2 * KMAX; i++) {
+        const bool live = (i < k) || (i >= KMAX && i < KMAX + k) || (i == 2 * KMAX);
+        if (live) {
+            double s = ksfd_wave_sum(acc[i]);
+            if (lane == 0) red[wv_][i] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= 2 * KMAX) {
+        const int i = threadIdx.x;
+        const bool live = (i < k) || (i >= KMAX && i < KMAX + k) || (i == 2 * KMAX);
+        if (live) {
+            double s = 0.0;
+            for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) s += red[q][i];
+            const int row = (i == 2 * KMAX) ? 2 * k : (i >= KMAX ? k + (i - KMAX) : i);
             part[(long long)row * gridDim.x + blockIdx.x] = s;
         }
     }
@@ -152,36 +237,54 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_reduce_rows(const double *__rest
 struct KCoef {
     double h[KSFD_MAXDOT];
 };
-template <int KMAX>
+template <int KMAX, int VW>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_gs_update(KVec g, double *__restrict__ w,
                                                           const double *__restrict__ V, long long vstride, int k,
                                                           KCoef C, double scale)
 {
     const long long base = (long long)blockIdx.y * g.plane + g.off;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
-        double s = w[base + p];
+    const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
+        typename KPack<VW>::T s = kload<VW>(w + base + p);
 #pragma unroll
         for (int i = 0; i < KMAX; i++)
-            if (i < k) s -= C.h[i] * V[(long long)i * vstride + base + p];
-        w[base + p] = s * scale;
+            if (i < k) {
+                const typename KPack<VW>::T vv = kload<VW>(V + (long long)i * vstride + base + p);
+#pragma unroll
+                for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) - C.h[i] * kget(vv, e));
+            }
+#pragma unroll
+        for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) * scale);
+        kstore<VW>(w + base + p, s);
     }
 }
 
-// x += sum_{i<k} y[i] V_i   (GMRES solution update)
-template <int KMAX>
+// x = beta*x + sum_{i<k} y[i] V_i   (GMRES solution update)
+template <int KMAX, int VW>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_basis_axpy(KVec g, double *__restrict__ x,
                                                            const double *__restrict__ V, long long vstride, int k,
                                                            KCoef C, double beta)
 {
     const long long base = (long long)blockIdx.y * g.plane + g.off;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
-        double s = beta == 0.0 ? 0.0 : beta * x[base + p];
+    const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
+        typename KPack<VW>::T s;
+        if (beta == 0.0) {
+#pragma unroll
+            for (int e = 0; e < VW; e++) kset(s, e, 0.0);
+        } else {
+            s = kload<VW>(x + base + p);
+#pragma unroll
+            for (int e = 0; e < VW; e++) kset(s, e, beta * kget(s, e));
+        }
 #pragma unroll
         for (int i = 0; i < KMAX; i++)
-            if (i < k) s += C.h[i] * V[(long long)i * vstride + base + p];
-        x[base + p] = s;
+            if (i < k) {
+                const typename KPack<VW>::T vv = kload<VW>(V + (long long)i * vstride + base + p);
+#pragma unroll
+                for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) + C.h[i] * kget(vv, e));
+            }
+        kstore<VW>(x + base + p, s);
     }
 }
 

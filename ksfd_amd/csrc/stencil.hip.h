@@ -486,3 +486,137 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_fused(KGeom G, KPhys P, KS
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Frozen-Jacobian path.  The Rosenbrock-W step keeps J = df/du(t_n, u_n) for all four stages and
+// every GMRES iteration (~40 Jacobian actions per step), so everything in J that depends only on
+// u_n is evaluated ONCE per step into a coefficient vector C of (3 + NL) planes
+//      C = [ rho (clamped), G, G_rho, G_U1 .. G_UNL ]
+// and the per-iteration kernel is pure stencil arithmetic: no log/tanh/divide.
+// Traffic per point: (3+NL) + (1+NL) reads + (1+NL) writes  (F=2: 64 B).
+// ---------------------------------------------------------------------------------------------
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jcoef(KGeom G, KPhys P, const double *__restrict__ u,
+                                                      double *__restrict__ C)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < G.plane; e += stride) {
+        double rho = ksfd_clamp(u[e], P.rhomin);
+        double U[NL], GU[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) U[l] = ksfd_clamp(u[(long long)(l + 1) * G.plane + e], P.Umin);
+        double g, gr;
+        ksfd_G<NL, true>(P, rho, U, g, gr, GU);
+        C[e] = rho;
+        C[G.plane + e] = g;
+        C[2 * G.plane + e] = gr;
+#pragma unroll
+        for (int l = 0; l < NL; l++) C[(long long)(3 + l) * G.plane + e] = GU[l];
+    }
+}
+
+// dG = G_rho v_rho + sum_l G_Ul v_Ul over the whole slab (generic path helper)
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double *__restrict__ C,
+                                                          const double *__restrict__ v, double *__restrict__ dG)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < G.plane; e += stride) {
+        double d = C[2 * G.plane + e] * v[e];
+#pragma unroll
+        for (int l = 0; l < NL; l++) d += C[(long long)(3 + l) * G.plane + e] * v[(long long)(l + 1) * G.plane + e];
+        dG[e] = d;
+    }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const double *__restrict__ C,
+                                                             const double *__restrict__ v, int mode, double shift,
+                                                             double *__restrict__ out)
+{
+    const KWaveJob J = ksfd_wave_job(G, S);
+    if (!J.valid) return;
+    double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
+    double nr[2], ng[2], nq[2], nv[2], nc[NL][2], nz[NL][2];
+
+    auto load_row = [&](long long r) {
+        const long long o = ksfd_rowoff(G, r) + J.c0;
+        double2 a = ksfd_ld2(C + o), b = ksfd_ld2(C + G.plane + o), c = ksfd_ld2(C + 2 * G.plane + o), w = ksfd_ld2(v + o);
+        nr[0] = a.x; nr[1] = a.y; ng[0] = b.x; ng[1] = b.y; nq[0] = c.x; nq[1] = c.y; nv[0] = w.x; nv[1] = w.y;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            double2 q = ksfd_ld2(C + (long long)(3 + l) * G.plane + o);
+            double2 z = ksfd_ld2(v + (long long)(l + 1) * G.plane + o);
+            nc[l][0] = q.x; nc[l][1] = q.y; nz[l][0] = z.x; nz[l][1] = z.y;
+        }
+    };
+    auto push_row = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                rw[s][e] = rw[s + 1][e]; gw[s][e] = gw[s + 1][e];
+                vw[s][e] = vw[s + 1][e]; ew[s][e] = ew[s + 1][e];
+#pragma unroll
+                for (int l = 0; l < NL; l++) zw[l][s][e] = zw[l][s + 1][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            double d = nq[e] * nv[e];
+#pragma unroll
+            for (int l = 0; l < NL; l++) { d += nc[l][e] * nz[l][e]; zw[l][4][e] = nz[l][e]; }
+            rw[4][e] = nr[e]; gw[4][e] = ng[e]; vw[4][e] = nv[e]; ew[4][e] = d;
+        }
+    };
+
+    for (int q = -2; q <= 1; q++) { load_row(J.r0 + q); push_row(); }
+    load_row(J.r0 + 2);
+    for (long long r = J.r0; r < J.r1; r++) {
+        push_row();
+        if (r + 1 < J.r1) load_row(r + 3);
+        const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
+        const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
+        const KX xv = ksfd_xnb(vw[2][0], vw[2][1]);
+        const KX xe = ksfd_xnb(ew[2][0], ew[2][1]);
+        double d1r[2], d1g[2], d1v[2], d1e[2], d2g[2], d2e[2];
+        ksfd_dx(rw[2][0], rw[2][1], xr, d1r[0], d1r[1]);
+        ksfd_dx(gw[2][0], gw[2][1], xg, d1g[0], d1g[1]);
+        ksfd_dx(vw[2][0], vw[2][1], xv, d1v[0], d1v[1]);
+        ksfd_dx(ew[2][0], ew[2][1], xe, d1e[0], d1e[1]);
+        ksfd_dxx(gw[2][0], gw[2][1], xg, d2g[0], d2g[1]);
+        ksfd_dxx(ew[2][0], ew[2][1], xe, d2e[0], d2e[1]);
+        double res[NL + 1][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double ih0 = P.inv_h[0], ih1 = P.inv_h[1];
+            const double yr = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * ih1;
+            const double yg = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * ih1;
+            const double yv = KSFD_D1(vw[0][e], vw[1][e], vw[3][e], vw[4][e]) * ih1;
+            const double ye = KSFD_D1(ew[0][e], ew[1][e], ew[3][e], ew[4][e]) * ih1;
+            const double lapG = d2g[e] * P.inv_h2[0] + KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[1];
+            const double lapE = d2e[e] * P.inv_h2[0] + KSFD_D2(ew[0][e], ew[1][e], ew[2][e], ew[3][e], ew[4][e]) * P.inv_h2[1];
+            const double jr = (d1v[e] * ih0) * (d1g[e] * ih0) + (d1r[e] * ih0) * (d1e[e] * ih0) + yv * yg + yr * ye +
+                              vw[2][e] * lapG + rw[2][e] * lapE;
+            res[0][e] = mode ? shift * vw[2][e] - jr : jr;
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const KX xz = ksfd_xnb(zw[l][2][0], zw[l][2][1]);
+            double d2z[2];
+            ksfd_dxx(zw[l][2][0], zw[l][2][1], xz, d2z[0], d2z[1]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double lap = d2z[e] * P.inv_h2[0] +
+                                   KSFD_D2(zw[l][0][e], zw[l][1][e], zw[l][2][e], zw[l][3][e], zw[l][4][e]) * P.inv_h2[1];
+                const double ju = -P.lig_gamma[l] * zw[l][2][e] + P.lig_s[l] * vw[2][e] + P.lig_D[l] * lap;
+                res[l + 1][e] = mode ? shift * zw[l][2][e] - ju : ju;
+            }
+        }
+        if (J.store) {
+            const long long o = (long long)G.ng * G.inner + r * G.nx + J.c0;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) ksfd_st2(out + (long long)c * G.plane + o, res[c][0], res[c][1]);
+        }
+    }
+}

@@ -118,7 +118,7 @@ def load():
     L.ksfd_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int32]
     L.ksfd_synchronize.argtypes = [vp]
     L.ksfd_bench_kernel.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
-    L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32]
+    L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     _lib = L
     return L
 
@@ -286,5 +286,6 @@ class KSFDHip:
         self._chk(self.L.ksfd_bench_kernel(self.h, cls, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
 
-    def set_tuning(self, use_fused=-1, yseg=0):
-        self._chk(self.L.ksfd_set_tuning(self.h, use_fused, yseg))
+    def set_tuning(self, use_fused=-1, yseg=0, yseg_jvp=None):
+        """use_fused: bit0 = fused 2-D kernels, bit1 = recompute (non-frozen) Jacobian action."""
+        self._chk(self.L.ksfd_set_tuning(self.h, use_fused, yseg, yseg if yseg_jvp is None else yseg_jvp))

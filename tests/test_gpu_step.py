@@ -20,14 +20,17 @@ def fixed_opts(z, **kw):
                                   ksp_max_it=4000, **kw)
 
 
+@pytest.mark.parametrize('orth,tuning', [(0, 1), (1, 1), (0, 3), (0, 0)])
 @pytest.mark.parametrize('name', [n for n in golden_cases('step_') if 'manufactured' not in n])
-def test_fixed_steps_vs_reference_lu_golden(name):
+def test_fixed_steps_vs_reference_lu_golden(name, orth, tuning):
+    """orth 0: CGS2 with algebraic second projection, 1: classic CGS2; tuning bit0 fused kernels, bit1 recompute J"""
     z = load_golden(name)
     cfg = ProblemConfig.from_golden(z)
     k = klib.KSFDHip(cfg)
+    k.set_tuning(use_fused=tuning)
     k.set_state(cijk_to_soa(z['u0']))
     t, h = float(z['t0']), float(z['h'])
-    opts = fixed_opts(z)
+    opts = fixed_opts(z, reserved=orth)
     for s in range(int(z['nsteps'])):
         t, hn, st, rc = k.step(t, h, opts)
         assert st.accepted and hn == h
