@@ -273,7 +273,7 @@ class SpatialExpression:
         return np.asarray(f(c[0], c[1], c[2], t), dtype=np.float64)
 
     def is_zero(self):
-        return self.expression == 0
+        return bool(self.expression.is_zero)
 
 
 def grid_coords(cfg):

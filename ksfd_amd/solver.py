@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""`python -m ksfd_amd.solver @options ...` -- counterpart of the reference's ksfdsolver2.main
+(ksfdsolver2.py:642-774) with the PETSc TS replaced by the HIP stepper.  Same command-line syntax."""
+import sys
+
+import numpy as np
+
+from . import options as opt
+from .initial import reference_rng, smoothstep_interpolate
+from .ts import Derivatives, implicitTS
+from .timeseries import TimeSeries
+
+
+def start_values(ps, cfg, rng):
+    """ksfdsolver2.py:580-639: rho = rho0(x) + interpolated coarse noise; U = U0(x) if given else rho*s/gamma."""
+    v = ps.values0
+    dim, shape = cfg.dim, cfg.n[:cfg.dim]
+    coarse = []
+    for a, key in enumerate(('randgridnw', 'randgridnh', 'randgridnd')[:dim]):
+        coarse.append(int(v[key]) if v[key] else max(1, shape[a] // 4))
+    murho0 = float(v['Nworms']) / (cfg.L[0] ** dim)
+    sigma = float(v['srho0'])
+    if sigma == 0.0:
+        noise = np.full(shape, murho0)
+    else:
+        z = rng.normal(size=tuple(coarse)) * sigma + murho0
+        noise = smoothstep_interpolate(z, shape)
+    coords = opt.grid_coords(cfg)
+    rho0 = v['rho0']
+    rho = np.broadcast_to(opt.SpatialExpression(ps, rho0)(ps.t0, coords), shape) + noise if rho0 else noise
+    fields = [rho]
+    names = ps.field_names()[1:]
+    for l, name in enumerate(names):
+        key = 'U0' + name[1:]
+        U0 = v.get(key)
+        if U0 is not None and U0 is not False and U0 != '':
+            fields.append(np.broadcast_to(opt.SpatialExpression(ps, U0)(ps.t0, coords), shape) + 0.0)
+        else:
+            fields.append(rho * (cfg.lig_s[l] / cfg.lig_gamma[l]))
+    return np.concatenate([f.ravel(order='F') for f in fields])          # SoA, x fastest
+
+
+def main(*args):
+    argv = list(args) if args else sys.argv
+    cl = opt.parse_commandline(argv[1:])
+    if cl.noperiodic:
+        raise ValueError('--periodic=false not implemented (as in the reference, ksfdsolver2.py:657-661)')
+    ps = opt.Params(cl)
+    if cl.showparams:
+        for k, val in ps.values0.items():
+            print('%s=%s' % (k, val))
+        return None
+    cfg = ps.problem_config()
+    sources = opt.decode_sources(cl.source, ps)
+    rng = reference_rng(cl.seed)
+    derivs = Derivatives(ps, cfg, sources)
+    from .layout import SOA
+    derivs.ks.set_state(start_values(ps, cfg, rng), SOA)
+    v = ps.values0
+    ts = implicitTS(derivs, t0=ps.t0, dt=float(v['dt']), tmax=float(v['tmax']),
+                    maxsteps=0 if cl.onestep else int(v['maxsteps']), rtol=float(v['rtol']), atol=float(v['atol']),
+                    opts=opt.step_opts_from(ps, cl.petsc), rng=rng)
+    ts.setMonitor(ts.printMonitor)
+    tseries = None
+    if cl.save:
+        tseries = TimeSeries(cl.save, derivs.grid, mode='w')
+        tseries.set_dt(float(v['dt']))
+        save, closer = ts.makeSaveMonitor(tseries)
+        ts.setMonitor(save)
+    try:
+        ts.solve()
+    finally:
+        if tseries is not None:
+            tseries.close()
+    if ts.comm.rank == 0:
+        print('SNES failures = ', ts.getSNESFailures())
+    return ts
+
+
+if __name__ == '__main__':
+    t = main()
+    if t is not None:
+        t.cleanup()

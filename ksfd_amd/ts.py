@@ -123,8 +123,21 @@ class Derivatives:
             self._coords = cs
         return self._coords
 
+    @staticmethod
+    def _src_is_zero(s):
+        if hasattr(s, 'is_zero'):
+            return s.is_zero()
+        e = getattr(s, 'expression', None)              # the reference's SpatialExpression
+        return bool(e is not None and getattr(e, 'is_zero', False))
+
+    def _src_eval(self, s, t):
+        try:
+            return s(t, self._local_coords())           # ksfd_amd.options.SpatialExpression
+        except TypeError:
+            return s(t)                                 # KSFD.SpatialExpression.__call__(t) (ksfdsym.py:1620-1655)
+
     def has_sources(self):
-        return any(not s.is_zero() for s in self.sources)
+        return any(not self._src_is_zero(s) for s in self.sources)
 
     def upload_sources(self, times):
         """times: the 4 stage times (or one time for all stages)."""
@@ -132,10 +145,10 @@ class Derivatives:
             return
         shape = self.grid.Slshape
         for c, s in enumerate(self.sources):
-            if s.is_zero():
+            if self._src_is_zero(s):
                 continue
             for i, t in enumerate(times):
-                v = np.broadcast_to(s(t, self._local_coords()), shape)
+                v = np.broadcast_to(self._src_eval(s, t), shape)
                 self.ks.set_source(c, v.ravel(order='F'), stage=i if len(times) > 1 else -1)
 
     def groom(self, farr):

@@ -1,0 +1,96 @@
+"""GPU, 2-3 ranks sharing cuda:0: the slab-decomposed path (ghost rows, halo exchange, global reductions,
+distributed GMRES/ROSW step) must reproduce the single-rank result.  Transport 2 (host callbacks over gloo) always;
+transport 1 (RCCL inside the library) when RCCL accepts several ranks on one device, else skipped."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import rel_l2
+from ksfd_amd.config import ProblemConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, size, port, shape, nlig, transport, outfile):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        from ksfd_amd import lib as klib
+        from ksfd_amd.dist import open_handle, local_slab, gather_slabs
+        dim = len(shape)
+        cfg = ProblemConfig.standard(dim, shape, L=[0.2 + 0.05 * a for a in range(dim)], nlig=nlig)
+        rng = np.random.default_rng(3)
+        N = cfg.N
+        rho = 9000 + 90 * rng.standard_normal(N)
+        u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] + rng.standard_normal(N) for l in range(nlig)])
+        v = rng.standard_normal(cfg.F * N)
+        try:
+            ks, keep = open_handle(cfg, rank, size, 0, transport=transport)
+        except Exception as e:                               # RCCL refuses duplicate devices on some stacks
+            if rank == 0:
+                np.savez(outfile, skip=np.array(repr(e)))
+            return
+        mine = lambda a: local_slab(a, cfg, rank, size)
+        got = {}
+        got['rhs'] = gather_slabs(ks.rhs(mine(u)), cfg)
+        got['jvp'] = gather_slabs(ks.jvp(mine(v), mine(u)), cfg)
+        ks.set_state(mine(u))
+        got['vmax'] = ks.velocity_max()
+        got['worms'] = ks.count_worms()
+        opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
+        t, h = 0.0, 0.02
+        stats = []
+        for _ in range(3):
+            t, h, st, rc = ks.step(t, h, opts)
+            stats.append((st.accepted, st.rejections, st.linear_its, st.wrms))
+        got['state'] = gather_slabs(ks.get_state(), cfg)
+        got['t'], got['h'] = t, h
+        ks.close()
+        if rank == 0:
+            one = klib.KSFDHip(cfg)
+            ref = {'rhs': one.rhs(u), 'jvp': one.jvp(v, u)}
+            one.set_state(u)
+            ref['vmax'] = one.velocity_max()
+            ref['worms'] = one.count_worms()
+            t1, h1 = 0.0, 0.02
+            for _ in range(3):
+                t1, h1, st1, rc = one.step(t1, h1, opts)
+            ref['state'], ref['t'], ref['h'] = one.get_state(), t1, h1
+            one.close()
+            np.savez(outfile, **{'got_' + k: np.asarray(got[k]) for k in got}, **{'ref_' + k: np.asarray(ref[k]) for k in ref})
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(size, shape, nlig, transport, tmp_path):
+    outfile = str(tmp_path / 'result.npz')       # results come back through a file: a queue would block on join
+    mp.spawn(_worker, args=(size, _free_port(), shape, nlig, transport, outfile), nprocs=size, join=True)
+    z = np.load(outfile)
+    if 'skip' in z:
+        pytest.skip('transport %s unavailable here: %s' % (transport, z['skip']))
+    for k in ('rhs', 'jvp', 'state'):
+        assert rel_l2(z['got_' + k], z['ref_' + k]) < 1e-11, k
+    for k in ('vmax', 'worms', 't', 'h'):
+        assert np.allclose(z['got_' + k], z['ref_' + k], rtol=1e-9, atol=0), (k, z['got_' + k], z['ref_' + k])
+
+
+@pytest.mark.parametrize('size,shape,nlig', [(2, (64, 48), 1), (3, (40, 36), 2), (2, (16, 12, 16), 1), (2, (33, 16), 1)])
+def test_slab_ranks_match_single_rank_host_transport(size, shape, nlig, tmp_path):
+    _run(size, shape, nlig, 'host', tmp_path)
+
+
+def test_slab_ranks_match_single_rank_rccl(tmp_path):
+    _run(2, (64, 48), 1, 'rccl', tmp_path)

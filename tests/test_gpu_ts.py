@@ -1,0 +1,109 @@
+"""GPU: the host-side mirror of KSFDTS / ksfdsolver2.main driving the HIP stepper from an @options file."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_l2
+from ksfd_amd import options as opt
+from ksfd_amd.layout import cijk_to_soa, petsc_to_cijk
+
+pytestmark = pytest.mark.gpu
+
+
+def test_solver_main_runs_options_file_with_monitors(tmp_path, capsys):
+    from ksfd_amd import solver
+    prefix = str(tmp_path / 'run' / 'ks2d')
+    ts = solver.main('ksfd', '@' + os.path.join(GOLDEN, 'options', 'ks2d_two_ligands.txt'), '--save=' + prefix)
+    out = capsys.readouterr().out
+    assert ts.getStepNumber() == 25 and not ts.diverged and ts.getSNESFailures() == 0
+    lines = [l for l in out.splitlines() if l.startswith('clock:')]
+    assert len(lines) == 26 and ' step  25 ' in lines[-1] and 'CFL=' in lines[-1]       # printMonitor format, ksfdts.py:337-353
+    assert ts.getTimeStep() > 1e-4                   # TSAdaptBasic ramped up from dt=1e-8 (x5 per step at first)
+    z = np.load(prefix + 's1r0.npz')
+    assert list(z['ks']) == list(range(26)) and z['data25'].shape == (3, 48, 48)
+    assert abs(z['times'][-1] - ts.getTime()) < 1e-15
+    # the stored (dof,nx,ny) C-order dataset is the device state
+    u = petsc_to_cijk(ts.getSolution().array, 3, (48, 48))
+    assert np.array_equal(z['data25'], u)
+    # worms are conserved by the scheme to rounding (periodic box, divergence form discretised consistently)
+    assert abs(u[0].sum() - z['data0'][0].sum()) < 1e-6 * z['data0'][0].sum()
+    ts.cleanup()
+
+
+def test_ts_loop_manufactured_with_time_dependent_source():
+    """KSFDTS.solve with a --source expression evaluated at the four ROSW stage times of every step."""
+    from ksfd_amd.ts import Derivatives, implicitTS
+    z = load_golden('step_1d_manufactured')
+    ns = opt.parse_commandline(['@' + os.path.join(GOLDEN, 'options', 'ks1d_manufactured.txt')])
+    ps = opt.Params(ns)
+    cfg = ps.problem_config()
+
+    class GoldenSource:                 # feeds the reference-generated source fields (src_v) for the stage times
+        def __init__(self, c):
+            self.c = c
+
+        def is_zero(self):
+            return not np.any(z['src_v'][:, self.c])
+
+        def __call__(self, t, coords):
+            i = int(np.argmin(np.abs(z['src_t'] - t)))
+            assert abs(z['src_t'][i] - t) < 1e-12
+            return z['src_v'][i, self.c]
+
+    d = Derivatives(ps, cfg, [GoldenSource(c) for c in range(3)])
+    d.ks.set_state(cijk_to_soa(z['u0']))
+    ts = implicitTS(d, t0=0.0, dt=1.0, tmax=19.5, maxsteps=100, rtol=1e-6, atol=0.01,
+                    opts=opt.step_opts_from(ps, ns.petsc))
+    ts.opts.ksp_rtol = 1e-12
+    seen = []
+    ts.setMonitor(lambda ts_, k, t, u: seen.append((k, t)))
+    ts.solve()
+    assert ts.getStepNumber() == 20 and abs(ts.getTime() - 20.0) < 1e-12     # STEPOVER: loop runs while t <= tmax
+    assert seen[0] == (0, 0.0) and seen[-1][0] == 20
+    assert rel_l2(d.ks.get_state(), cijk_to_soa(z['uN'])) < 1e-10
+    assert np.abs(d.ks.get_state() - cijk_to_soa(z['exactN'])).max() < 2e-6
+    ts.cleanup()
+
+
+def test_noise_injection_and_conserve_worms():
+    """KSFD/ksfdts.py:218-223, 258-284: rho *= exp(sqrt(rate*dt) N(0,1)) from the reference's RNG stream, then rescale."""
+    from ksfd_amd.ts import Derivatives, implicitTS
+    from ksfd_amd.initial import reference_rng
+
+    def run(vrate):
+        ns = opt.parse_commandline(['dim=2', 'nelements=32', 'width=0.3', 'height=0.3', 'sigma=0.02357', 's2=sigma**2/2',
+                                    'alpha_1=1500', 'beta_1=5.56e-4', 's_1_1=0.01', 'gamma_1_1=0.01', 'D_1_1=1e-6',
+                                    'variance_rate=%g' % vrate, 'variance_interval=0.01', 'conserve_worms=True',
+                                    'dt=0.004', 'maxsteps=4', 'atol=0.01', 'rtol=1e-6',
+                                    '--petsc', '-ts_adapt_type', 'none', '--'])
+        ps = opt.Params(ns)
+        cfg = ps.problem_config()
+        d = Derivatives(ps, cfg)
+        rho = 9000 + 90 * np.random.default_rng(1).standard_normal(cfg.N)
+        d.ks.set_state(np.concatenate([rho, rho]))
+        ts = implicitTS(d, t0=0.0, dt=0.004, tmax=1.0, maxsteps=4, rtol=1e-6, atol=0.01,
+                        opts=opt.step_opts_from(ps, ns.petsc), rng=reference_rng(5))
+        N0 = d.ks.count_worms()
+        hist = []
+        ts.setMonitor(lambda ts_, k, t, u: hist.append((k, t, u.array.reshape((2, 32, 32), order='F').copy())))
+        ts.solve()
+        N1 = d.ks.count_worms()
+        ts.cleanup()
+        return hist, N0, N1
+
+    plain, N0, N1 = run(0.0)
+    noisy, M0, M1 = run(1e-4)
+    # conserve_worms rescales to the start-of-solve count right after the injection (the non-conservative
+    # form of the flux lets the total drift by ~1e-6 between injections, as in the reference)
+    assert abs(noisy[3][2][0].sum() - M0) < 1e-11 * M0
+    for k in (1, 2):                                      # identical until the first injection
+        assert np.array_equal(plain[k][2], noisy[k][2])
+    # noise fires when t/variance_interval has advanced by >= 1 since lastvart: first after step 3 (t = 0.012)
+    assert abs(noisy[3][1] - 0.012) < 1e-15
+    ratio = noisy[3][2][0] / plain[3][2][0]
+    z = reference_rng(5).normal(size=(32, 32))            # same stream and shape as ksfdts.py:279-280
+    sd = np.sqrt(1e-4 * 0.012)
+    corr = np.log(ratio) - sd * z                         # = log of the uniform conserve_worms correction
+    assert np.ptp(corr) < 1e-12 and abs(corr.mean()) < 1e-3
+    assert np.array_equal(noisy[3][2][1], plain[3][2][1])  # U untouched
