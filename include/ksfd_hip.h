@@ -91,7 +91,7 @@ typedef struct ksfd_step_opts {
     double safety, reject_safety; /* 0.9, 0.5 */
     double ksp_rtol, ksp_atol;  /* GMRES: stop at ||r|| <= max(ksp_rtol*||b||, ksp_atol) */
     int32_t ksp_restart, ksp_max_it;
-    int32_t pc_type;            /* 0 none (round 1) */
+    int32_t pc_type;            /* 0 none; 1 geometric multigrid V cycle (2-D, one rank); 2 = multigrid only when stiff (default) */
     int32_t reserved;           /* 0: CGS2 with algebraic second projection (default); 1: classic two-pass CGS2 */
 } ksfd_step_opts;
 
@@ -108,7 +108,7 @@ typedef struct ksfd_step_stats {
 } ksfd_step_stats;
 
 /* Per-kernel-class timing gathered with HIP events on the library's compute stream. */
-#define KSFD_NKCLASS 12
+#define KSFD_NKCLASS 13
 typedef struct ksfd_profile {
     double ms[KSFD_NKCLASS];       /* accumulated device time */
     double bytes[KSFD_NKCLASS];    /* accumulated algorithmic bytes */
@@ -172,6 +172,9 @@ int ksfd_synchronize(ksfd_handle *h);
 int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms, double *bytes_per_launch);
 /* use_fused: bit0 fused 2-D kernels, bit1 set = recompute (non-frozen) Jacobian action; yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
+/* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the
+ * Chebyshev bound, smoothing interval ratio lambda_max/lambda_min, coarsest-grid reduction target */
+int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t power_its, double ratio, double coarse_tol);
 
 #ifdef __cplusplus
 }

@@ -13,19 +13,34 @@
 
 #include "../../include/ksfd_hip.h"
 #include "stencil.hip.h"
+#include "mg.hip.h"
 #include "transport.h"
 
 // ------------------------------------------------------------------------------------------------
 // kernel classes for the profile
 enum { KC_RHS = 0, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE,
-       KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO };
+       KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG };
 static const char *kc_names[KSFD_NKCLASS] = { "rhs", "jvp", "multidot", "gs_update", "lincomb", "basis_axpy",
-                                              "rosw_finish", "reduce", "gfield", "velocity", "misc", "halo" };
+                                              "rosw_finish", "reduce", "gfield", "velocity", "misc", "halo", "mg" };
 extern "C" const char *ksfd_kernel_class_name(int32_t c) { return (c >= 0 && c < KSFD_NKCLASS) ? kc_names[c] : "?"; }
 
 static thread_local std::string g_create_error;
 
 struct EvPair { hipEvent_t a, b; int cls; };
+
+// one grid of the multigrid hierarchy (level 0 = the solver's own grid; see mg.hip.h)
+struct MGLevel {
+    KGeom G;
+    KPhys P;
+    KVec kv;
+    int64_t vlen = 0;
+    int nblk = 1;
+    double *coef = nullptr;    // [rho, G, G_rho, G_U..] planes (level 0 aliases the handle's)
+    double *dinv = nullptr;    // F*F planes
+    double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *Ad = nullptr, *dG = nullptr;
+    double lam_max = 2.3;
+    double ratio = 60.0;       // lambda_max/lambda_min estimate (used on the coarsest grid)
+};
 
 struct ksfd_handle {
     ksfd_config cfg;
@@ -68,6 +83,14 @@ struct ksfd_handle {
     std::vector<hipEvent_t> pool;
     ksfd_profile prof;
     double bytes_acc = 0.0;
+
+    // multigrid preconditioner
+    std::vector<MGLevel> mg;
+    bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
+    double mg_shift = -1.0;      // shift the block diagonals / eigen-bounds were built for
+    bool mg_coef_valid = false;  // coarse coefficient planes match the current frozen state
+    int mg_nu = 2, mg_ncoarse = 400, mg_power_its = 8;   // smoothing sweeps, cap on coarsest-grid sweeps, power iterations
+    double mg_ratio = 6.0, mg_coarse_tol = 1e-2;
 
     // ROSW tableau (PETSc transformed form)
     double At[4][4], Ginv[4][4], bt[4], b2t[4], asum[4];
@@ -452,6 +475,9 @@ static int download(ksfd_handle *h, const double *dev, int layout, double *host)
     return KSFD_OK;
 }
 
+static void mg_free(ksfd_handle *h);
+static int mg_build(ksfd_handle *h);
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -468,6 +494,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     if (h->hres) hipHostFree(h->hres);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
+    mg_free(h);
     delete h->tr;
     if (h->st) hipStreamDestroy(h->st);
     delete h;
@@ -538,6 +565,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         h->tr = make_transport(dist, G.F, G.inner, terr);
         if (!h->tr) CFAIL(KSFD_ECOMM, "transport %d: %s", dist->transport, terr.c_str());
     }
+    if (mg_build(h)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
     if (hipStreamSynchronize(h->st) != hipSuccess) CFAIL(KSFD_EHIP, "stream sync failed in create");
 #undef CFAIL
     *out = h;
@@ -732,6 +760,226 @@ extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
 }
 
 // ------------------------------------------------------------------------------------------------
+// multigrid preconditioner (host side; kernels and rationale in mg.hip.h)
+// ------------------------------------------------------------------------------------------------
+static void mg_free(ksfd_handle *h)
+{
+    for (size_t l = 0; l < h->mg.size(); l++) {
+        MGLevel &L = h->mg[l];
+        double *bufs[] = { l ? L.coef : nullptr, L.dinv, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG };
+        for (double *b : bufs) if (b) hipFree(b);
+    }
+    h->mg.clear();
+    h->mg_ok = false;
+}
+
+static int mg_build(ksfd_handle *h)
+{
+    if (h->G.dim != 2 || h->size != 1) return KSFD_OK;
+    int nl = h->P.nlig, F = h->G.F;
+    long long nx = h->G.nx, ny = h->G.ny;
+    KPhys P = h->P;
+    for (int l = 0;; l++) {
+        MGLevel L;
+        L.G = h->G; L.G.nx = nx; L.G.ny = ny; L.G.inner = nx; L.G.sloc = ny; L.G.plane = nx * ny; L.G.nloc = nx * ny;
+        L.P = P;
+        L.kv.plane = L.G.plane; L.kv.off = 0; L.kv.nloc = L.G.nloc; L.kv.nf = F;
+        L.vlen = (int64_t)F * L.G.plane;
+        L.nblk = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
+        if (l == 0) L.coef = h->coef;
+        else if (alloc_d(h, &L.coef, (int64_t)(3 + nl) * L.G.plane) || alloc_d(h, &L.x, L.vlen) || alloc_d(h, &L.b, L.vlen)) return KSFD_ENOMEM;
+        if (alloc_d(h, &L.dinv, (int64_t)F * F * L.G.plane) || alloc_d(h, &L.r, L.vlen) || alloc_d(h, &L.d, L.vlen) ||
+            alloc_d(h, &L.Ad, L.vlen) || alloc_d(h, &L.dG, L.G.plane)) return KSFD_ENOMEM;
+        h->mg.push_back(L);
+        if ((nx % 2) || (ny % 2) || nx / 2 < 8 || ny / 2 < 8) break;
+        nx /= 2; ny /= 2;
+        for (int a = 0; a < 3; a++) { P.inv_h[a] *= 0.5; P.inv_h2[a] *= 0.25; }
+    }
+    h->mg_ok = h->mg.size() >= 2;
+    return KSFD_OK;
+}
+
+// out = J v | shift v - J v | yadd - (shift v - J v) on level L
+static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double shift, double *out, const double *yadd)
+{
+    const KGeom &G = L.G;
+    const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
+    const double by = 8.0 * ((3 + h->P.nlig) + 2.0 * G.F + (mode == 2 ? G.F : 0)) * (double)G.nloc;
+    if (h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
+        KStrips K;
+        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+        K.yseg = h->yseg_jvp;
+        K.nseg = (int)((G.sloc + K.yseg - 1) / K.yseg);
+        long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
+        K.nblocks = (int)((nb + 7) / 8 * 8);
+        Scope sc(h, cls, by);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, cls, by + 8.0 * G.plane);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)L.coef, v, L.dG));
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, L.P, (const double *)L.coef, v, (const double *)(L.coef + G.plane), (const double *)L.dG, mode, shift, out, yadd));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int mg_norm(ksfd_handle *h, MGLevel &L, const double *v, double *nrm)
+{
+    const bool v2 = (L.G.nloc % 2 == 0);
+    const int nb = v2 ? (L.nblk + 1) / 2 : L.nblk;
+    {
+        Scope sc(h, KC_MG, 8.0 * L.vlen);
+        if (v2) hipLaunchKernelGGL((k_multidot<4, 2>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.kv, v, v, L.vlen, 0, h->part);
+        else hipLaunchKernelGGL((k_multidot<4, 1>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.kv, v, v, L.vlen, 0, h->part);
+    }
+    HIPCHK(h, hipGetLastError());
+    int rc = reduce_rows(h, 1, nb, 0);
+    if (rc) return rc;
+    *nrm = sqrt(h->hres[0]);
+    return KSFD_OK;
+}
+
+// restrict coefficient planes down the hierarchy (once per frozen state)
+static int mg_restrict_coefs(ksfd_handle *h)
+{
+    const int np = 3 + h->P.nlig;
+    for (size_t l = 0; l + 1 < h->mg.size(); l++) {
+        MGLevel &Lf = h->mg[l], &Lc = h->mg[l + 1];
+        int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_MG, 8.0 * np * (Lf.G.nloc + Lc.G.nloc));
+        hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, (const double *)Lf.coef, Lf.G.plane, Lc.coef, Lc.G.plane);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->mg_coef_valid = true;
+    return KSFD_OK;
+}
+
+// block-diagonal inverses and Chebyshev upper bounds for this shift
+static int mg_setup_shift(ksfd_handle *h, double shift)
+{
+    int rc;
+    for (size_t l = 0; l < h->mg.size(); l++) {
+        MGLevel &L = h->mg[l];
+        const int F = L.G.F;
+        int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_MG, 8.0 * (3 + h->P.nlig + F * F) * L.G.nloc);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_blockdiag_inv<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G, L.P, (const double *)L.coef, shift, L.dinv));
+        }
+        HIPCHK(h, hipGetLastError());
+        // power iteration on Dinv*A: v in L.d, A v in L.Ad, Dinv A v in L.r
+        hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)L.vlen, L.d);
+        double nv = 1.0, lam = 2.0;
+        if ((rc = mg_norm(h, L, L.d, &nv))) return rc;
+        for (int it = 0; it < h->mg_power_its; it++) {
+            if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
+            {
+                Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, (const double *)L.Ad, 1.0, L.r));
+            }
+            double nw;
+            if ((rc = mg_norm(h, L, L.r, &nw))) return rc;
+            if (!(nw > 0.0) || !(nv > 0.0)) break;
+            lam = nw / nv;
+            // v <- w / |w|
+            Scope sc(h, KC_MG, 16.0 * L.vlen);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, (const double *)L.Ad, 1.0 / nw, L.d));
+            nv = 1.0;
+        }
+        L.lam_max = 1.15 * lam;
+        if (l + 1 == h->mg.size()) {
+            int nbr = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 256);
+            hipLaunchKernelGGL(k_ratio_est, dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, (long long)L.G.nloc, (const double *)L.dinv, shift, h->part);
+            if ((rc = reduce_rows(h, 1, nbr, 1))) return rc;
+            L.ratio = std::max(30.0, 1.5 * L.lam_max * h->hres[0]);
+        }
+    }
+    h->mg_shift = shift;
+    return KSFD_OK;
+}
+
+// Chebyshev smoothing of A x = b on level L with Dinv; nu sweeps; eigen-interval [lmax/ratio, lmax]
+static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, double *x, int nu, bool zero_init, double ratio)
+{
+    int rc;
+    const int F = L.G.F;
+    const int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    const double lmax = L.lam_max, lmin = lmax / ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig1 = theta / delta;
+    const double *res = b;
+    if (zero_init) {
+        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)L.vlen, h->st));
+    } else {
+        if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;        // r = b - A x
+        res = L.r;
+    }
+    {
+        Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, res, 1.0 / theta, L.d));
+    }
+    if (zero_init && nu > 1) HIPCHK(h, hipMemcpyAsync(L.r, b, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
+    double rho = 1.0 / sig1;
+    for (int k = 1; k <= nu; k++) {
+        if (k == nu) {
+            // x += d only
+            const double *xs[2] = { x, L.d };
+            KLin LL;
+            for (int t = 0; t < 6; t++) { LL.x[t] = t < 2 ? xs[t] : nullptr; LL.a[t] = t < 2 ? 1.0 : 0.0; }
+            Scope sc(h, KC_MG, 24.0 * L.vlen);
+            hipLaunchKernelGGL((k_lincomb<2, 1>), dim3(L.nblk, F), dim3(KSFD_BLOCK), 0, h->st, L.kv, LL, x);
+            break;
+        }
+        if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
+        const double rhon = 1.0 / (2.0 * sig1 - rho);
+        {
+            Scope sc(h, KC_MG, 8.0 * (7 * F + F * F) * L.G.nloc);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, x, L.r, L.d, (const double *)L.Ad, rhon * rho, 2.0 * rhon / delta));
+        }
+        rho = rhon;
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x)
+{
+    int rc;
+    MGLevel &L = h->mg[l];
+    if (l + 1 == h->mg.size()) {
+        // coarsest grid: Chebyshev over the whole spectrum, enough sweeps for a ~1e-2 reduction
+        int sweeps = (int)ceil(0.5 * sqrt(L.ratio) * log(2.0 / h->mg_coarse_tol));
+        sweeps = std::min(std::max(sweeps, 4), h->mg_ncoarse);
+        return mg_smooth(h, L, shift, b, x, sweeps, true, L.ratio);
+    }
+    MGLevel &Lc = h->mg[l + 1];
+    if ((rc = mg_smooth(h, L, shift, b, x, h->mg_nu, true, h->mg_ratio))) return rc;
+    if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;
+    int nbc = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    {
+        Scope sc(h, KC_MG, 8.0 * L.G.F * (L.G.nloc + Lc.G.nloc));
+        hipLaunchKernelGGL(k_restrict2d, dim3(nbc), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.ny, (const double *)L.r, L.G.plane, Lc.b, Lc.G.plane);
+    }
+    if ((rc = mg_vcycle(h, l + 1, shift, Lc.b, Lc.x))) return rc;
+    int nbf = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    {
+        Scope sc(h, KC_MG, 8.0 * L.G.F * (2 * L.G.nloc + Lc.G.nloc));
+        hipLaunchKernelGGL(k_prolong_add2d, dim3(nbf), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.ny, (const double *)Lc.x, Lc.G.plane, x, L.G.plane);
+    }
+    HIPCHK(h, hipGetLastError());
+    return mg_smooth(h, L, shift, b, x, h->mg_nu, false, h->mg_ratio);
+}
+
+// out = M^-1 in  (one V cycle)
+static int mg_precond(ksfd_handle *h, double shift, const double *in, double *out)
+{
+    int rc;
+    if (!h->mg_coef_valid && (rc = mg_restrict_coefs(h))) return rc;
+    if (h->mg_shift != shift && (rc = mg_setup_shift(h, shift))) return rc;
+    return mg_vcycle(h, 0, shift, in, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // matrix-free GMRES(m) for (shift I - J(u)) x = b, x0 = 0  -- replaces -ksp_type preonly -pc_type lu
 // (options84:58-60).  Classical Gram-Schmidt applied twice (CGS2), one fused multi-dot + one fused
 // update kernel per pass; the new vector's norm comes from the second pass by Pythagoras.
@@ -739,8 +987,12 @@ extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
 struct LinStats { int its; double rel; };
 
 static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
-                 const ksfd_step_opts *o, LinStats *ls)
+                 const ksfd_step_opts *o, LinStats *ls, bool use_pc)
 {
+    // use_pc: right preconditioning with one multigrid V cycle, w = A (M^-1 v_j), x = M^-1 (V y)
+    auto apply_A = [&](const double *vin, double *wout) -> int {
+        return h->use_frozen ? op_jvp_frozen(h, vin, 1, shift, wout) : op_jvp(h, ustate, vin, 1, shift, wout);
+    };
     const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
     const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
     const int64_t vs = h->vlen;
@@ -763,7 +1015,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         // V0 = r / beta
         if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
         else {
-            if ((rc = halo(h, x)) || (rc = (h->use_frozen ? op_jvp_frozen(h, x, 1, shift, V) : op_jvp(h, ustate, x, 1, shift, V)))) return rc;     // V0 = A x
+            if ((rc = halo(h, x)) || (rc = apply_A(x, V))) return rc;     // V0 = A x
             const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
             if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;                                  // r = b - A x
             if ((rc = op_multidot(h, V, V, 0))) return rc;
@@ -780,7 +1032,9 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         bool done = false;
         for (; j < m && total < maxit; j++) {
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
-            if ((rc = halo(h, vj)) || (rc = (h->use_frozen ? op_jvp_frozen(h, vj, 1, shift, w) : op_jvp(h, ustate, vj, 1, shift, w)))) return rc;
+            if (use_pc) {
+                if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = apply_A(h->t1, w))) return rc;
+            } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
             const int k = j + 1;
             if (o->reserved == 1) {
                 // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
@@ -854,7 +1108,11 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             for (int q = i + 1; q < j; q++) s -= H[(size_t)(m + 1) * q + i] * y[q];
             y[i] = s / H[(size_t)(m + 1) * i + i];
         }
-        if ((rc = op_basis_axpy(h, x, V, j, y.data(), first ? 0.0 : 1.0))) return rc;
+        if (use_pc) {
+            if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
+            if (first) { if ((rc = op_copy(h, x, h->t1))) return rc; }
+            else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
+        } else if ((rc = op_basis_axpy(h, x, V, j, y.data(), first ? 0.0 : 1.0))) return rc;
         first = false;
         if (done || total >= maxit) break;
     }
@@ -877,7 +1135,7 @@ extern "C" void ksfd_default_step_opts(ksfd_step_opts *o)
     // (tools/acc_vs_ksp.py); the north-star tolerance is 1e-8.  PETSc's own KSP default is 1e-5.
     o->ksp_rtol = 1e-6; o->ksp_atol = 1e-50;
     o->ksp_restart = 30; o->ksp_max_it = 2000;
-    o->pc_type = 0;
+    o->pc_type = 2;    // 0 none, 1 multigrid always, 2 multigrid when the step is stiff (2-D, single rank)
 }
 
 // One TSStep_RosW attempt loop (PETSc rosw.c restated; tableau/derivation in oracle/ksfd_oracle.c).
@@ -900,8 +1158,17 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     if ((rc = op_copy(h, h->usave, h->u))) goto out;
     if ((rc = halo(h, h->u))) goto out;
     if (h->use_frozen && (rc = op_jcoef(h, h->u))) goto out;
+    h->mg_coef_valid = false;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
+        // stiffness estimate h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~8
+        bool use_pc = false;
+        if (h->mg_ok && h->use_frozen && opts->pc_type) {
+            double dmax = h->P.s2, lap = 0.0;
+            for (int l = 0; l < h->P.nlig; l++) dmax = std::max(dmax, h->P.lig_D[l]);
+            for (int a = 0; a < h->G.dim; a++) lap += (16.0 / 3.0) * h->P.inv_h2[a];
+            use_pc = opts->pc_type == 1 || (dmax * lap / shift > 8.0);
+        }
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
             if (i > 0) {
@@ -922,7 +1189,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 if (nt > 1 && (rc = op_lincomb(h, nt, xs, a, h->bvec))) break;
             }
             LinStats ls;
-            rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls);
+            rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc);
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
         }
@@ -1004,6 +1271,17 @@ extern "C" int ksfd_get_profile(ksfd_handle *h, ksfd_profile *p, int32_t reset)
     prof_resolve(h);
     *p = h->prof;
     if (reset) memset(&h->prof, 0, sizeof h->prof);
+    return KSFD_OK;
+}
+extern "C" int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t power_its, double ratio, double coarse_tol)
+{
+    if (!h) return KSFD_EINVAL;
+    if (nu > 0) h->mg_nu = nu;
+    if (ncoarse_max > 0) h->mg_ncoarse = ncoarse_max;
+    if (power_its > 0) h->mg_power_its = power_its;
+    if (ratio > 1.0) h->mg_ratio = ratio;
+    if (coarse_tol > 0.0) h->mg_coarse_tol = coarse_tol;
+    h->mg_shift = -1.0;
     return KSFD_OK;
 }
 extern "C" int ksfd_synchronize(ksfd_handle *h)

@@ -1,0 +1,187 @@
+// Geometric multigrid preconditioner for the stage systems (shift*I - J) y = b of the Rosenbrock-W step.
+//
+// Stands in for what `-pc_type lu -pc_factor_mat_solver_type mumps` (options84:58-60) gives the reference:
+// a solve whose cost does not blow up when h*gamma*lambda_max(J) >> 1 (late-time steps h ~ 1..1e4).
+// Matrix-free and rediscretised: level l uses the SAME analytic Jacobian-action kernels with the frozen
+// coefficient planes [rho, G, G_rho, G_U] full-weighted onto a grid of spacing 2^l h.  Smoother: Chebyshev
+// iteration preconditioned by the inverse of the point-block (F x F) diagonal of A_l.  Vertex-centred full
+// coarsening on the periodic box, full-weighting restriction, bilinear prolongation, V(nu,nu) cycle, fixed
+// polynomial smoothing on the coarsest grid -- every piece is a fixed linear operator, so plain
+// right-preconditioned GMRES applies.  2-D, single rank (round 1).
+#pragma once
+#include "stencil.hip.h"
+
+// coarse(I,J) = sum_{a,b in -1..1} w_a w_b fine(2I+a, 2J+b), w = (1/4, 1/2, 1/4); periodic.
+__global__ void __launch_bounds__(KSFD_BLOCK) k_restrict2d(int nplanes, long long nxf, long long nyf,
+                                                           const double *__restrict__ fine, long long fplane,
+                                                           double *__restrict__ coarse, long long cplane)
+{
+    const long long nxc = nxf >> 1, nyc = nyf >> 1, nc = nxc * nyc;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nc; p += stride) {
+        const long long I = p % nxc, J = p / nxc;
+        const long long i0 = 2 * I, j0 = 2 * J;
+        const long long im = (i0 + nxf - 1) % nxf, ip = (i0 + 1) % nxf;
+        const long long jm = (j0 + nyf - 1) % nyf, jp = (j0 + 1) % nyf;
+        for (int c = 0; c < nplanes; c++) {
+            const double *f = fine + (long long)c * fplane;
+            const double s = 0.25 * f[i0 + nxf * j0] +
+                             0.125 * (f[im + nxf * j0] + f[ip + nxf * j0] + f[i0 + nxf * jm] + f[i0 + nxf * jp]) +
+                             0.0625 * (f[im + nxf * jm] + f[ip + nxf * jm] + f[im + nxf * jp] + f[ip + nxf * jp]);
+            coarse[(long long)c * cplane + p] = s;
+        }
+    }
+}
+
+// fine += P coarse (bilinear interpolation, periodic)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long long nxf, long long nyf,
+                                                              const double *__restrict__ coarse, long long cplane,
+                                                              double *__restrict__ fine, long long fplane)
+{
+    const long long nxc = nxf >> 1, nyc = nyf >> 1, nf = nxf * nyf;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nf; p += stride) {
+        const long long i = p % nxf, j = p / nxf;
+        const long long I = i >> 1, J = j >> 1;
+        const long long I1 = (i & 1) ? (I + 1) % nxc : I, J1 = (j & 1) ? (J + 1) % nyc : J;
+        for (int c = 0; c < nplanes; c++) {
+            const double *q = coarse + (long long)c * cplane;
+            const double v = 0.25 * (q[I + nxc * J] + q[I1 + nxc * J] + q[I + nxc * J1] + q[I1 + nxc * J1]);
+            fine[(long long)c * fplane + p] += v;
+        }
+    }
+}
+
+// Inverse of the point-block diagonal of A = shift*I - J (F x F per point, row-major planes dinv[(r*F+c)*plane]):
+//   D_rr = shift - (lapG + rho*G_rho*c2),  D_rUl = -rho*G_Ul*c2,  D_Ulr = -s_l,  D_UlUl = shift + gamma_l - D_l*c2
+// with c2 = sum_a (-30/12)/h_a^2 the centre weight of the 4th-order Laplacian.
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, const double *__restrict__ C, double shift,
+                                                              double *__restrict__ dinv)
+{
+    constexpr int F = NL + 1;
+    const double *Gb = C + G.plane;
+    double c2 = 0.0;
+    for (int a = 0; a < G.dim; a++) c2 += -2.5 * P.inv_h2[a];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
+        long long i, j, k;
+        ksfd_decode(G, p, i, j, k);
+        double lapG = 0.0;
+        for (int a = 0; a < G.dim; a++) {
+            KNbr n = ksfd_nbr(G, a, i, j, k);
+            lapG += KSFD_D2(Gb[n.m2], Gb[n.m1], Gb[n.c], Gb[n.p1], Gb[n.p2]) * P.inv_h2[a];
+        }
+        const double rho = C[p], gr = C[2 * G.plane + p];
+        double M[F][F], Inv[F][F];
+#pragma unroll
+        for (int r = 0; r < F; r++)
+#pragma unroll
+            for (int c = 0; c < F; c++) { M[r][c] = 0.0; Inv[r][c] = (r == c) ? 1.0 : 0.0; }
+        M[0][0] = shift - (lapG + rho * gr * c2);
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            M[0][l + 1] = -rho * C[(long long)(3 + l) * G.plane + p] * c2;
+            M[l + 1][0] = -P.lig_s[l];
+            M[l + 1][l + 1] = shift + P.lig_gamma[l] - P.lig_D[l] * c2;
+        }
+        // Gauss-Jordan without pivoting (the blocks are strongly diagonally dominated by shift + diffusion)
+#pragma unroll
+        for (int q = 0; q < F; q++) {
+            const double ip = 1.0 / M[q][q];
+#pragma unroll
+            for (int c = 0; c < F; c++) { M[q][c] *= ip; Inv[q][c] *= ip; }
+#pragma unroll
+            for (int r = 0; r < F; r++) {
+                if (r == q) continue;
+                const double f = M[r][q];
+#pragma unroll
+                for (int c = 0; c < F; c++) { M[r][c] -= f * M[q][c]; Inv[r][c] -= f * Inv[q][c]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < F; r++)
+#pragma unroll
+            for (int c = 0; c < F; c++) dinv[(long long)(r * F + c) * G.plane + p] = Inv[r][c];
+    }
+}
+
+// z = scale * Dinv r
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long long plane, const double *__restrict__ dinv,
+                                                           const double *__restrict__ r, double scale, double *__restrict__ z)
+{
+    constexpr int F = NL + 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double rv[F];
+#pragma unroll
+        for (int c = 0; c < F; c++) rv[c] = r[(long long)c * plane + p];
+#pragma unroll
+        for (int a = 0; a < F; a++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < F; c++) s += dinv[(long long)(a * F + c) * plane + p] * rv[c];
+            z[(long long)a * plane + p] = scale * s;
+        }
+    }
+}
+
+// One Chebyshev recurrence step after Ad = A d is known:
+//   x += d ; r -= Ad ; d = c1*d + c2*(Dinv r)
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_step(long long n, long long plane, const double *__restrict__ dinv,
+                                                          double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
+                                                          const double *__restrict__ Ad, double c1, double c2)
+{
+    constexpr int F = NL + 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double rv[F], dv[F];
+#pragma unroll
+        for (int c = 0; c < F; c++) {
+            const long long o = (long long)c * plane + p;
+            dv[c] = d[o];
+            x[o] += dv[c];
+            rv[c] = r[o] - Ad[o];
+            r[o] = rv[c];
+        }
+#pragma unroll
+        for (int a = 0; a < F; a++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < F; c++) s += dinv[(long long)(a * F + c) * plane + p] * rv[c];
+            d[(long long)a * plane + p] = c1 * dv[a] + c2 * s;
+        }
+    }
+}
+
+// deterministic pseudo-random fill for the power iteration
+__global__ void __launch_bounds__(KSFD_BLOCK) k_hash_fill(long long n, double *__restrict__ v)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        unsigned long long z = (unsigned long long)p * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+        z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+        v[p] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+
+// per-block max over points of 1/(shift * [Dinv]_00): ~ largest diagonal-to-shift ratio, i.e. an estimate of
+// lambda_max/lambda_min of Dinv*A on a grid whose smoothest modes see only the shift
+__global__ void __launch_bounds__(KSFD_BLOCK) k_ratio_est(long long n, const double *__restrict__ dinv00, double shift,
+                                                          double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE];
+    double m = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) m = fmax(m, 1.0 / fabs(shift * dinv00[p]));
+    m = ksfd_wave_max(m);
+    if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red[threadIdx.x / KSFD_WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) t = fmax(t, red[q]);
+        part[blockIdx.x] = t;
+    }
+}

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
                                                             const double *__restrict__ v,
                                                             const double *__restrict__ Gb,
                                                             const double *__restrict__ dGb, int mode, double shift,
-                                                            double *__restrict__ out)
+                                                            double *__restrict__ out, const double *__restrict__ yadd = nullptr)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
@@ -170,11 +170,15 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
         }
         const long long o = (long long)G.ng * G.inner + p;
         double jr = acc + v0 * lapG + rho0 * lapdG;
-        out[o] = mode ? shift * v0 - jr : jr;
+        double o0 = mode ? shift * v0 - jr : jr;
+        if (mode == 2) o0 = yadd[o] - o0;
+        out[o] = o0;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             double ju = -P.lig_gamma[l] * V0[l] + P.lig_s[l] * v0 + P.lig_D[l] * lapV[l];
-            out[(long long)(l + 1) * G.plane + o] = mode ? shift * V0[l] - ju : ju;
+            double ol = mode ? shift * V0[l] - ju : ju;
+            if (mode == 2) ol = yadd[(long long)(l + 1) * G.plane + o] - ol;
+            out[(long long)(l + 1) * G.plane + o] = ol;
         }
     }
 }
@@ -532,8 +536,9 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const double *__restrict__ C,
                                                              const double *__restrict__ v, int mode, double shift,
-                                                             double *__restrict__ out)
+                                                             double *__restrict__ out, const double *__restrict__ yadd = nullptr)
 {
+    // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x)
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;
     double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
@@ -616,7 +621,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         if (J.store) {
             const long long o = (long long)G.ng * G.inner + r * G.nx + J.c0;
 #pragma unroll
-            for (int c = 0; c <= NL; c++) ksfd_st2(out + (long long)c * G.plane + o, res[c][0], res[c][1]);
+            for (int c = 0; c <= NL; c++) {
+                double a = res[c][0], b = res[c][1];
+                if (mode == 2) { const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o); a = yy.x - a; b = yy.y - b; }
+                ksfd_st2(out + (long long)c * G.plane + o, a, b);
+            }
         }
     }
 }

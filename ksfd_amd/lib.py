@@ -13,13 +13,13 @@ from .layout import PETSC, SOA, HDF5  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libksfd_hip.so')
-NKCLASS = 12
+NKCLASS = 13
 
 OK, EINVAL, EHIP, ENOMEM, ELINEAR, ENAN, EREJECT, ECOMM = range(8)
 
 # kernel classes of ksfd_profile / ksfd_bench_kernel
 KC_RHS, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE, \
-    KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO = range(12)
+    KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG = range(13)
 
 
 class KSFDError(RuntimeError):
@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
     'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho',
     'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
-    'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning',
+    'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params',
 ]
 
 
@@ -119,6 +119,7 @@ def load():
     L.ksfd_synchronize.argtypes = [vp]
     L.ksfd_bench_kernel.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    L.ksfd_set_mg_params.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]
     _lib = L
     return L
 
@@ -285,6 +286,9 @@ class KSFDHip:
         ms, by = C.c_double(), C.c_double()
         self._chk(self.L.ksfd_bench_kernel(self.h, cls, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
+
+    def set_mg_params(self, nu=0, ncoarse_max=0, power_its=0, ratio=0.0, coarse_tol=0.0):
+        self._chk(self.L.ksfd_set_mg_params(self.h, nu, ncoarse_max, power_its, ratio, coarse_tol))
 
     def set_tuning(self, use_fused=-1, yseg=0, yseg_jvp=None):
         """use_fused: bit0 = fused 2-D kernels, bit1 = recompute (non-frozen) Jacobian action."""

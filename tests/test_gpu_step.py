@@ -113,3 +113,65 @@ def test_adaptive_controller_matches_oracle_formula():
     assert not st2.accepted and st2.rejections == 1 and hn2 < 50.0 and t2 == t
     assert np.array_equal(k.get_state(), ko.Oracle(cfg).groom(before))    # rolled back
     k.close()
+
+
+@pytest.mark.parametrize('name', ['step_2d_n1_stiff', 'step_2d_n1_mild'])
+def test_multigrid_preconditioned_steps_vs_reference_lu_golden(name):
+    """pc_type=1: right-preconditioned GMRES with the geometric-multigrid V cycle gives the same steps"""
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    k = klib.KSFDHip(cfg)
+    k.set_state(cijk_to_soa(z['u0']))
+    t, h = float(z['t0']), float(z['h'])
+    opts = fixed_opts(z, pc_type=1)
+    its = 0
+    for s in range(int(z['nsteps'])):
+        t, hn, st, rc = k.step(t, h, opts)
+        its += st.linear_its
+        if s == 0:
+            assert rel_l2(k.get_state(), cijk_to_soa(z['u1'])) < STEP_TOL
+    assert rel_l2(k.get_state(), cijk_to_soa(z['uN'])) < STEP_TOL
+    k.close()
+
+
+def test_multigrid_makes_very_stiff_steps_cheap():
+    """h*gamma*lambda_max ~ 1e5: what the reference leaves to LU.  Multigrid keeps GMRES at a handful of iterations
+    per stage; the result equals the oracle's dense-LU step."""
+    cfg = ProblemConfig.standard(2, (32, 32), L=(0.08, 0.08), nlig=2)
+    rng = np.random.default_rng(4)
+    N = 32 * 32
+    rho = 9000 + 90 * rng.standard_normal(N)       # srho0=90 as in the reference's runs (options84:31)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(2)])
+    h = 50.0
+    un, err, wr, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=2))
+    assert st.linear_its <= 4 * 16, st.linear_its
+    assert rel_l2(k.get_state(), un) < 1e-9
+    k.set_state(u)
+    t, hn, st0, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=0,
+                                                           ksp_max_it=4000), raise_on_error=False)
+    assert rc != 0 or st0.linear_its > 5 * st.linear_its        # unpreconditioned: far more work or no convergence
+    k.close()
+
+
+def test_long_adaptive_run_reaches_large_steps():
+    """dt0=1e-8 -> the controller grows h by orders of magnitude (options80/81-style runs); auto pc keeps it solvable"""
+    cfg = ProblemConfig.standard(2, (64, 64), L=(0.17, 0.17), nlig=1)
+    rng = np.random.default_rng(9)
+    N = 64 * 64
+    rho = 9000 + 90 * rng.standard_normal(N)
+    k = klib.KSFDHip(cfg)
+    k.set_state(np.concatenate([rho, rho]))
+    opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
+    t, h, its, rej = 0.0, 1e-8, [], 0
+    for s in range(60):
+        t, h, st, rc = k.step(t, h, opts)
+        its.append(st.linear_its)
+        rej += st.rejections
+    assert t > 5.0 and h > 0.5, (t, h)
+    assert max(its) < 400, its
+    u = k.get_state()
+    assert np.isfinite(u).all() and u.min() > 0
+    k.close()
