@@ -40,13 +40,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--n', type=int, default=4096)
+    ap.add_argument('--grid', dest='n', type=int, default=4096, help='points per axis')
     ap.add_argument('--nlig', type=int, default=1)
     ap.add_argument('--dt', type=float, default=0.05, help='first trial step (the controller adapts from here)')
     ap.add_argument('--fixed-h', type=float, default=0.0, help='>0: -ts_adapt_type none with this step')
     ap.add_argument('--ksp-rtol', type=float, default=1e-6,
                     help='GMRES relative residual; 1e-6 keeps the fields within ~1e-10 rel-L2 of a 1e-12 solve')
-    ap.add_argument('--transport', default='auto', choices=['auto', 'rccl', 'host'])
+    ap.add_argument('--transport', default=os.environ.get('KSFD_TRANSPORT', 'auto'), choices=['auto', 'rccl', 'host'])
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend for launch/timing; gloo + --transport host lets several ranks share one GPU (rehearsal)')
+    ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-n', type=int, default=512)
     ap.add_argument('--yseg', type=int, default=0)
@@ -67,12 +70,15 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
     host_group = None
+    dev = 0 if (world == 1 or args.share_gpu) else local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        host_group = dist.new_group(backend='gloo')
-    dev = local_rank if world > 1 else 0
+        torch.cuda.set_device(dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+            host_group = dist.new_group(backend='gloo')
+        else:
+            dist.init_process_group('gloo')
 
     cfg = build_problem(args.n, args.nlig)
     u0 = start_values(cfg)                                  # global SoA state (identical on every rank)
@@ -121,7 +127,7 @@ def main():
     prof = ks.profile()
     ks.set_profiling(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -129,7 +135,8 @@ def main():
         N = cfg.N
         value = N * args.steps / elapsed
         # dominant kernel = largest share of device time in the timed region
-        dom = max(prof, key=lambda k: prof[k]['ms'])
+        compute = [k for k in prof if k not in ('halo', 'reduce', 'misc')]       # transport / tiny kernels are not roofline material
+        dom = max(compute, key=lambda k: prof[k]['ms'])
         d = prof[dom]
         per_launch_bytes = d['bytes'] / max(d['launches'], 1)
         per_launch_ms = d['ms'] / max(d['launches'], 1)
@@ -148,7 +155,8 @@ def main():
                                                                       'TSAdaptBasic rtol=1e-6 atol=0.01 from dt=%g' % args.dt),
                        'grid': [args.n, args.n], 'fields': cfg.F, 'ksp_rtol': args.ksp_rtol,
                        'h_mean': float(np.mean(hs)), 'gmres_its_per_step': its / args.steps, 'rejections': rej,
-                       't_end': t, 'parallelism': 'slab%d' % world},
+                       't_end': t, 'parallelism': 'slab%d' % world,
+                       'transport': type(keep).__name__ if keep is not None else 'none'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'bytes_per_launch': per_launch_bytes, 'ms_per_launch': per_launch_ms,

@@ -1,0 +1,29 @@
+"""Production-style run: adaptive integration from dt=1e-8 far into the aggregation phase (options81-style)."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from ksfd_amd import lib as klib
+from ksfd_amd.config import ProblemConfig
+from ksfd_amd.initial import start_values
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+nlig = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+cfg = ProblemConfig.standard(2, (n, n), L=(n / 384.0, n / 384.0), nlig=nlig)      # options81 spacing (width 1 at 384)
+ks = klib.KSFDHip(cfg)
+ks.set_state(start_values(cfg))
+opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
+t, h = 0.0, 1e-8
+T0 = time.perf_counter()
+tot_its = 0
+for s in range(nsteps):
+    t0 = time.perf_counter()
+    t, h, st, rc = ks.step(t, h, opts, raise_on_error=False)
+    tot_its += st.linear_its
+    if rc:
+        print('STOP rc', rc, ks.last_error()); break
+    if s % 10 == 0 or st.rejections:
+        vm = ks.velocity_max()
+        print('step %4d t %.4e h_next %.3e its %4d rej %d wrms %.2e  %.1f ms  vmax %.2e' % (s, t, h, st.linear_its, st.rejections, st.wrms, 1e3 * (time.perf_counter() - t0), vm[0]), flush=True)
+    if t > 2e5: break
+u = ks.get_state()
+print('done: steps %d t %.4e total its %d wall %.1f s  rho min %.3g max %.3g' % (s + 1, t, tot_its, time.perf_counter() - T0, u[:n*n].min(), u[:n*n].max()))
