@@ -76,6 +76,7 @@ struct ksfd_handle {
     int use_fused = 1;
     int yseg = 32;        // rows per wave segment, RHS kernel (measured best at 4096^2)
     int yseg_jvp = 16;    // same for the Jacobian-action kernels
+    int zseg = 32;        // planes per wave segment, 3-D z-marching kernel
 
     // profile
     bool profiling = false;
@@ -348,6 +349,21 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         KStrips K = make_strips(h, true);
         Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out));
+    } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
+        }
+        K3D K;
+        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+        K.nygrp = (int)((G.ny + 3) / 4);
+        K.zseg = h->zseg;
+        K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
+        long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
+        K.nblocks = (int)((nb3 + 7) / 8 * 8);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -664,7 +680,12 @@ extern "C" int ksfd_jvp(ksfd_handle *h, const double *uh, const double *vh, doub
     if (uh) { if ((rc = upload(h, uh, layout, h->t1))) return rc; uin = h->t1; }
     if ((rc = upload(h, vh, layout, h->t2))) return rc;
     if ((rc = halo(h, uin)) || (rc = halo(h, h->t2))) return rc;
-    if ((rc = op_jvp(h, uin, h->t2, 0, 0.0, h->t3))) return rc;
+    if (!uh && h->use_frozen) {
+        // the path the stepper uses: coefficients of the stored state once, then the frozen-coefficient kernels
+        if ((rc = op_jcoef(h, h->u))) return rc;
+        h->mg_coef_valid = false;
+        if ((rc = op_jvp_frozen(h, h->t2, 0, 0.0, h->t3))) return rc;
+    } else if ((rc = op_jvp(h, uin, h->t2, 0, 0.0, h->t3))) return rc;
     return download(h, h->t3, layout, outh);
 }
 

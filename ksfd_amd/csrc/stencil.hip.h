@@ -629,3 +629,154 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// 3-D frozen Jacobian action: z-marching.  A wave owns a strip of 128 columns (2 per lane) of ONE
+// y row and marches down a segment of z planes with 5-plane register windows of rho, G, v_rho, dG, v_U
+// (z-neighbours); x-neighbours by wave shuffles; the 4 y-neighbour rows of the centre plane are read
+// with 16-B loads that hit L1/L2 (the 4 waves of a block own 4 adjacent rows).  dG is a stored plane
+// (k_dg_frozen) because the y-neighbours need it.  Traffic: dg pass 8N(3+2n) + this pass 8N(5+n+F) + F writes.
+// ---------------------------------------------------------------------------------------------
+struct K3D {
+    int nstrips, nygrp, nzseg, zseg, nblocks;
+};
+
+__device__ __forceinline__ long long ksfd_planeoff(const KGeom &G, long long k)
+{
+    const long long pl = G.nx * G.ny;
+    if (G.wrap_slow) {
+        k %= G.sloc;
+        if (k < 0) k += G.sloc;
+        return k * pl;
+    }
+    return (k + G.ng) * pl;
+}
+
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K3D S, const double *__restrict__ C,
+                                                             const double *__restrict__ v, const double *__restrict__ dG,
+                                                             int mode, double shift, double *__restrict__ out,
+                                                             const double *__restrict__ yadd = nullptr)
+{
+    const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x >> 6;
+    const long long bid = ksfd_xcd_remap(blockIdx.x, S.nblocks);
+    const long long nb_valid = (long long)S.nstrips * S.nygrp * S.nzseg;
+    if (bid >= nb_valid) return;
+    const int strip = (int)(bid % S.nstrips);
+    const long long ygrp = (bid / S.nstrips) % S.nygrp, zs = bid / ((long long)S.nstrips * S.nygrp);
+    const long long y = ygrp * (KSFD_BLOCK / KSFD_WAVE) + wv;
+    if (y >= G.ny) return;                                   // whole wave; no block barrier in this kernel
+    const long long half = G.nx >> 1;
+    const long long xs = 2 * ((long long)strip * half / S.nstrips), xe = 2 * ((long long)(strip + 1) * half / S.nstrips);
+    long long c0 = (xs - 2 + 2 * lane) % G.nx;
+    if (c0 < 0) c0 += G.nx;
+    const bool store = lane >= 1 && lane <= (int)((xe - xs) >> 1);
+    const long long k0 = zs * S.zseg, k1 = k0 + S.zseg < G.sloc ? k0 + S.zseg : G.sloc;
+    const long long rowc = y * G.nx + c0;
+    long long yo[4];                                          // row offsets of y-2, y-1, y+1, y+2 (periodic)
+    {
+        const int dm[4] = { -2, -1, 1, 2 };
+#pragma unroll
+        for (int q = 0; q < 4; q++) { long long yy = (y + dm[q]) % G.ny; if (yy < 0) yy += G.ny; yo[q] = yy * G.nx + c0; }
+    }
+    const double *Cr = C, *Cg = C + G.plane;
+    double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];
+    double nr[2], ng[2], nv[2], ne[2], nz[NL][2];
+    auto load_plane = [&](long long k) {
+        const long long o = ksfd_planeoff(G, k) + rowc;
+        double2 a = ksfd_ld2(Cr + o), b = ksfd_ld2(Cg + o), w = ksfd_ld2(v + o), e = ksfd_ld2(dG + o);
+        nr[0] = a.x; nr[1] = a.y; ng[0] = b.x; ng[1] = b.y; nv[0] = w.x; nv[1] = w.y; ne[0] = e.x; ne[1] = e.y;
+#pragma unroll
+        for (int l = 0; l < NL; l++) { double2 z = ksfd_ld2(v + (long long)(l + 1) * G.plane + o); nz[l][0] = z.x; nz[l][1] = z.y; }
+    };
+    auto push = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                rw[s][e] = rw[s + 1][e]; gw[s][e] = gw[s + 1][e]; vw[s][e] = vw[s + 1][e]; ew[s][e] = ew[s + 1][e];
+#pragma unroll
+                for (int l = 0; l < NL; l++) zw[l][s][e] = zw[l][s + 1][e];
+            }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            rw[4][e] = nr[e]; gw[4][e] = ng[e]; vw[4][e] = nv[e]; ew[4][e] = ne[e];
+#pragma unroll
+            for (int l = 0; l < NL; l++) zw[l][4][e] = nz[l][e];
+        }
+    };
+    for (int q = -2; q <= 1; q++) { load_plane(k0 + q); push(); }
+    load_plane(k0 + 2);
+    for (long long k = k0; k < k1; k++) {
+        push();
+        if (k + 1 < k1) load_plane(k + 3);
+        const long long po = ksfd_planeoff(G, k);
+        // y-neighbour rows of the centre plane
+        double2 yr[4], yg[4], yv[4], ye[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            yr[q] = ksfd_ld2(Cr + po + yo[q]); yg[q] = ksfd_ld2(Cg + po + yo[q]);
+            yv[q] = ksfd_ld2(v + po + yo[q]);  ye[q] = ksfd_ld2(dG + po + yo[q]);
+        }
+        const KX xr = ksfd_xnb(rw[2][0], rw[2][1]), xg = ksfd_xnb(gw[2][0], gw[2][1]);
+        const KX xv = ksfd_xnb(vw[2][0], vw[2][1]), xe_ = ksfd_xnb(ew[2][0], ew[2][1]);
+        double d1r[2], d1g[2], d1v[2], d1e[2], d2g[2], d2e[2];
+        ksfd_dx(rw[2][0], rw[2][1], xr, d1r[0], d1r[1]);
+        ksfd_dx(gw[2][0], gw[2][1], xg, d1g[0], d1g[1]);
+        ksfd_dx(vw[2][0], vw[2][1], xv, d1v[0], d1v[1]);
+        ksfd_dx(ew[2][0], ew[2][1], xe_, d1e[0], d1e[1]);
+        ksfd_dxx(gw[2][0], gw[2][1], xg, d2g[0], d2g[1]);
+        ksfd_dxx(ew[2][0], ew[2][1], xe_, d2e[0], d2e[1]);
+        double res[NL + 1][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double ih0 = P.inv_h[0], ih1 = P.inv_h[1], ih2 = P.inv_h[2];
+#define KY(arr, q) (e ? arr[q].y : arr[q].x)
+            const double yr1 = KSFD_D1(KY(yr, 0), KY(yr, 1), KY(yr, 2), KY(yr, 3)) * ih1;
+            const double yg1 = KSFD_D1(KY(yg, 0), KY(yg, 1), KY(yg, 2), KY(yg, 3)) * ih1;
+            const double yv1 = KSFD_D1(KY(yv, 0), KY(yv, 1), KY(yv, 2), KY(yv, 3)) * ih1;
+            const double ye1 = KSFD_D1(KY(ye, 0), KY(ye, 1), KY(ye, 2), KY(ye, 3)) * ih1;
+            const double yg2 = KSFD_D2(KY(yg, 0), KY(yg, 1), gw[2][e], KY(yg, 2), KY(yg, 3)) * P.inv_h2[1];
+            const double ye2 = KSFD_D2(KY(ye, 0), KY(ye, 1), ew[2][e], KY(ye, 2), KY(ye, 3)) * P.inv_h2[1];
+            const double zr1 = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * ih2;
+            const double zg1 = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * ih2;
+            const double zv1 = KSFD_D1(vw[0][e], vw[1][e], vw[3][e], vw[4][e]) * ih2;
+            const double ze1 = KSFD_D1(ew[0][e], ew[1][e], ew[3][e], ew[4][e]) * ih2;
+            const double zg2 = KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[2];
+            const double ze2 = KSFD_D2(ew[0][e], ew[1][e], ew[2][e], ew[3][e], ew[4][e]) * P.inv_h2[2];
+            const double lapG = d2g[e] * P.inv_h2[0] + yg2 + zg2;
+            const double lapE = d2e[e] * P.inv_h2[0] + ye2 + ze2;
+            const double jr = (d1v[e] * ih0) * (d1g[e] * ih0) + (d1r[e] * ih0) * (d1e[e] * ih0) + yv1 * yg1 + yr1 * ye1 +
+                              zv1 * zg1 + zr1 * ze1 + vw[2][e] * lapG + rw[2][e] * lapE;
+            res[0][e] = mode ? shift * vw[2][e] - jr : jr;
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const double *vl = v + (long long)(l + 1) * G.plane + po;
+            double2 yz[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) yz[q] = ksfd_ld2(vl + yo[q]);
+            const KX xz = ksfd_xnb(zw[l][2][0], zw[l][2][1]);
+            double d2z[2];
+            ksfd_dxx(zw[l][2][0], zw[l][2][1], xz, d2z[0], d2z[1]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double lap = d2z[e] * P.inv_h2[0] +
+                                   KSFD_D2(KY(yz, 0), KY(yz, 1), zw[l][2][e], KY(yz, 2), KY(yz, 3)) * P.inv_h2[1] +
+                                   KSFD_D2(zw[l][0][e], zw[l][1][e], zw[l][2][e], zw[l][3][e], zw[l][4][e]) * P.inv_h2[2];
+                const double ju = -P.lig_gamma[l] * zw[l][2][e] + P.lig_s[l] * vw[2][e] + P.lig_D[l] * lap;
+                res[l + 1][e] = mode ? shift * zw[l][2][e] - ju : ju;
+            }
+#undef KY
+        }
+        if (store) {
+            const long long o = (long long)G.ng * G.inner + k * G.nx * G.ny + rowc;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) {
+                double a = res[c][0], b = res[c][1];
+                if (mode == 2) { const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o); a = yy.x - a; b = yy.y - b; }
+                ksfd_st2(out + (long long)c * G.plane + o, a, b);
+            }
+        }
+    }
+}

@@ -100,3 +100,30 @@ def test_outer_loop_helpers():
     assert np.allclose(g2[:N], g[:N] * 0.5 * f, rtol=1e-15)
     assert np.array_equal(g2[N:], g[N:])
     k.close()
+
+
+@pytest.mark.parametrize('shape,nlig', [((64, 48), 1), ((250, 36), 2), ((16, 16, 12), 2), ((132, 10, 37), 1),
+                                         ((24, 9, 40), 3), ((37, 21), 1), ((96,), 1)])
+def test_frozen_coefficient_jacobian_action_vs_oracle(shape, nlig):
+    """u=None: the stepper's own path -- coefficient planes of the stored state once (k_jcoef), then the
+    frozen-coefficient kernels (2-D strips, 3-D z-marching, generic)."""
+    dim = len(shape)
+    if nlig <= 2:
+        cfg = ProblemConfig.standard(dim, shape, L=[0.3 * (a + 1) for a in range(dim)], nlig=nlig)
+    else:
+        cfg = ProblemConfig(dim=dim, n=shape, L=(1.0, 0.7, 0.9)[:dim], lig_group=[0, 1, 0], lig_w=[1.0, 1.0, 0.5],
+                            lig_s=[0.01, 0.001, 0.02], lig_gamma=[0.01, 0.001, 0.03], lig_D=[1e-6, 1e-5, 2e-6],
+                            grp_alpha=[1500.0, 1500.0], grp_beta=[5.56e-4, -5.56e-4])
+    rng = np.random.default_rng(8)
+    N = int(np.prod(shape))
+    u = 9000 + 900 * rng.standard_normal(cfg.F * N)
+    u[3] = np.nan
+    u[N + 5] = -1.0
+    v = rng.standard_normal(cfg.F * N)
+    want = ko.Oracle(cfg).jvp(u, v)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    for fused in (1, 0):
+        k.set_tuning(use_fused=fused)
+        assert rel_l2(k.jvp(v), want) < TOL
+    k.close()
