@@ -52,7 +52,7 @@ def main():
                     help='torch.distributed backend for launch/timing; gloo + --transport host lets several ranks share one GPU (rehearsal)')
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-n', type=int, default=1536)
+    ap.add_argument('--cpu-sample-n', type=int, default=3072)
     ap.add_argument('--yseg', type=int, default=0)
     args = ap.parse_args()
 

@@ -90,6 +90,10 @@ struct ksfd_handle {
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
     double mg_shift = -1.0;      // shift the block diagonals / eigen-bounds were built for
     bool mg_coef_valid = false;  // coarse coefficient planes match the current frozen state
+    hipGraphExec_t mg_graph = nullptr;   // captured coarse part of the V cycle (levels >= 1) for mg_graph_shift/x
+    double mg_graph_shift = -1.0, mg_graph_bytes = 0.0;
+    double *mg_graph_x = nullptr;
+    bool capturing = false, mg_use_graph = true;
     int mg_nu = 2, mg_ncoarse = 400, mg_power_its = 8;   // smoothing sweeps, cap on coarsest-grid sweeps, power iterations
     double mg_ratio = 6.0, mg_coarse_tol = 1e-2;
 
@@ -125,7 +129,7 @@ static hipEvent_t ev_get(ksfd_handle *h)
 }
 struct Scope {
     ksfd_handle *h; EvPair p; bool on;
-    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling)
+    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling && !h_->capturing)
     {
         h->bytes_acc += bytes;
         h->prof.bytes[cls] += bytes;
@@ -527,6 +531,9 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     memset(h->src, 0, sizeof h->src);
     memset(&h->prof, 0, sizeof h->prof);
     h->cfg = *cfg;
+    // the caller keeps ownership of the tables: the handle holds numeric copies (fill_phys), never these pointers
+    h->cfg.lig_group = nullptr; h->cfg.lig_w = h->cfg.lig_s = h->cfg.lig_gamma = h->cfg.lig_D = nullptr;
+    h->cfg.grp_alpha = h->cfg.grp_beta = nullptr;
     int rc = fill_phys(h, cfg);
     if (rc) { g_create_error = h->err; delete h; return rc; }
     h->rank = dist ? dist->rank : 0;
@@ -609,6 +616,8 @@ extern "C" int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg)
     if (cfg->dim != h->cfg.dim || cfg->nlig != h->cfg.nlig) return fail(h, KSFD_EINVAL, "update_params cannot change dim/nlig");
     for (int a = 0; a < 3; a++) if (cfg->n[a] != h->cfg.n[a]) return fail(h, KSFD_EINVAL, "update_params cannot change the grid");
     h->cfg = *cfg;
+    h->cfg.lig_group = nullptr; h->cfg.lig_w = h->cfg.lig_s = h->cfg.lig_gamma = h->cfg.lig_D = nullptr;
+    h->cfg.grp_alpha = h->cfg.grp_beta = nullptr;
     return fill_phys(h, cfg);
 }
 
@@ -683,7 +692,7 @@ extern "C" int ksfd_jvp(ksfd_handle *h, const double *uh, const double *vh, doub
     if (!uh && h->use_frozen) {
         // the path the stepper uses: coefficients of the stored state once, then the frozen-coefficient kernels
         if ((rc = op_jcoef(h, h->u))) return rc;
-        h->mg_coef_valid = false;
+        h->mg_coef_valid = false; h->mg_shift = -1.0;
         if ((rc = op_jvp_frozen(h, h->t2, 0, 0.0, h->t3))) return rc;
     } else if ((rc = op_jvp(h, uin, h->t2, 0, 0.0, h->t3))) return rc;
     return download(h, h->t3, layout, outh);
@@ -785,6 +794,7 @@ extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
 // ------------------------------------------------------------------------------------------------
 static void mg_free(ksfd_handle *h)
 {
+    if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
     for (size_t l = 0; l < h->mg.size(); l++) {
         MGLevel &L = h->mg[l];
         double *bufs[] = { l ? L.coef : nullptr, L.dinv, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG };
@@ -917,6 +927,7 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
         }
     }
     h->mg_shift = shift;
+    h->mg_graph_shift = -1.0;        // Chebyshev bounds changed: the captured coarse cycle is stale
     return KSFD_OK;
 }
 
@@ -963,19 +974,13 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
     return KSFD_OK;
 }
 
-static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x)
+static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x);
+
+// coarse-grid correction of level l: restrict L.r, recurse, prolong-add into x
+static int mg_coarse_correction(ksfd_handle *h, size_t l, double shift, double *x)
 {
     int rc;
-    MGLevel &L = h->mg[l];
-    if (l + 1 == h->mg.size()) {
-        // coarsest grid: Chebyshev over the whole spectrum, enough sweeps for a ~1e-2 reduction
-        int sweeps = (int)ceil(0.5 * sqrt(L.ratio) * log(2.0 / h->mg_coarse_tol));
-        sweeps = std::min(std::max(sweeps, 4), h->mg_ncoarse);
-        return mg_smooth(h, L, shift, b, x, sweeps, true, L.ratio);
-    }
-    MGLevel &Lc = h->mg[l + 1];
-    if ((rc = mg_smooth(h, L, shift, b, x, h->mg_nu, true, h->mg_ratio))) return rc;
-    if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;
+    MGLevel &L = h->mg[l], &Lc = h->mg[l + 1];
     int nbc = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     {
         Scope sc(h, KC_MG, 8.0 * L.G.F * (L.G.nloc + Lc.G.nloc));
@@ -988,6 +993,48 @@ static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, do
         hipLaunchKernelGGL(k_prolong_add2d, dim3(nbf), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.ny, (const double *)Lc.x, Lc.G.plane, x, L.G.plane);
     }
     HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x)
+{
+    int rc;
+    MGLevel &L = h->mg[l];
+    if (l + 1 == h->mg.size()) {
+        // coarsest grid: Chebyshev over the whole spectrum, enough sweeps for a ~1e-2 reduction
+        int sweeps = (int)ceil(0.5 * sqrt(L.ratio) * log(2.0 / h->mg_coarse_tol));
+        sweeps = std::min(std::max(sweeps, 4), h->mg_ncoarse);
+        return mg_smooth(h, L, shift, b, x, sweeps, true, L.ratio);
+    }
+    if ((rc = mg_smooth(h, L, shift, b, x, h->mg_nu, true, h->mg_ratio))) return rc;
+    if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;
+    if (l == 0 && h->mg_use_graph && !h->capturing) {
+        // everything below level 0 touches only fixed buffers: capture it once per shift into a hipGraph and
+        // replay it (a V cycle has ~15 launches per level; on small grids they are pure launch latency)
+        if (!h->mg_graph || h->mg_graph_shift != shift || h->mg_graph_x != x) {
+            if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
+            hipGraph_t g = nullptr;
+            const double b0 = h->bytes_acc;
+            HIPCHK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+            h->capturing = true;
+            rc = mg_coarse_correction(h, 0, shift, x);
+            h->capturing = false;
+            hipError_t e = hipStreamEndCapture(h->st, &g);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess || !g) return fail(h, KSFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            e = hipGraphInstantiate(&h->mg_graph, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (e != hipSuccess) { h->mg_graph = nullptr; return fail(h, KSFD_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+            h->mg_graph_bytes = h->bytes_acc - b0;
+            h->bytes_acc = b0;
+            h->mg_graph_shift = shift;
+            h->mg_graph_x = x;
+        }
+        {
+            Scope sc(h, KC_MG, h->mg_graph_bytes);
+            HIPCHK(h, hipGraphLaunch(h->mg_graph, h->st));
+        }
+    } else if ((rc = mg_coarse_correction(h, l, shift, x))) return rc;
     return mg_smooth(h, L, shift, b, x, h->mg_nu, false, h->mg_ratio);
 }
 
@@ -1179,7 +1226,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     if ((rc = op_copy(h, h->usave, h->u))) goto out;
     if ((rc = halo(h, h->u))) goto out;
     if (h->use_frozen && (rc = op_jcoef(h, h->u))) goto out;
-    h->mg_coef_valid = false;
+    h->mg_coef_valid = false; h->mg_shift = -1.0;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
         // stiffness estimate h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~8
@@ -1302,6 +1349,7 @@ extern "C" int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_ma
     if (power_its > 0) h->mg_power_its = power_its;
     if (ratio > 1.0) h->mg_ratio = ratio;
     if (coarse_tol > 0.0) h->mg_coarse_tol = coarse_tol;
+    h->mg_use_graph = power_its != -7;     // power_its = -7: eager launches (debug / A-B timing)
     h->mg_shift = -1.0;
     return KSFD_OK;
 }
