@@ -80,7 +80,7 @@ def parse_commandline(argv):
     p.add_argument('--seed', type=int, default=793817931)
     p.add_argument('--source', type=str, action='append', default=[])
     p.add_argument('params', type=str, nargs='*')
-    ns = p.parse_args(args)
+    ns = p.parse_intermixed_args(args)          # name=value parameters and --options may be interleaved
     ns.petsc = petsc
     return ns
 

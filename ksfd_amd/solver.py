@@ -54,10 +54,22 @@ def main(*args):
     sources = opt.decode_sources(cl.source, ps)
     rng = reference_rng(cl.seed)
     derivs = Derivatives(ps, cfg, sources)
-    from .layout import SOA
-    derivs.ks.set_state(start_values(ps, cfg, rng), SOA)
+    from .layout import SOA, HDF5
     v = ps.values0
-    ts = implicitTS(derivs, t0=ps.t0, dt=float(v['dt']), tmax=float(v['tmax']),
+    t_start, dt0, k0 = ps.t0, float(v['dt']), 0
+    resuming = cl.resume or cl.restart
+    if resuming:
+        # ksfdsolver2.py:525-578: last point of the series; --resume keeps its time and dt, --restart starts at t0
+        from .timeseries import read_last
+        k_last, t_last, data, info, _ = read_last(resuming)
+        derivs.ks.set_state(np.ascontiguousarray(data).ravel(), HDF5)
+        if cl.resume:
+            t_start = t_last
+            if 'dt' not in ps.given and 'dt' in info:
+                dt0 = float(info['dt'])
+    else:
+        derivs.ks.set_state(start_values(ps, cfg, rng), SOA)
+    ts = implicitTS(derivs, t0=t_start, dt=dt0, tmax=float(v['tmax']),
                     maxsteps=0 if cl.onestep else int(v['maxsteps']), rtol=float(v['rtol']), atol=float(v['atol']),
                     opts=opt.step_opts_from(ps, cl.petsc), rng=rng)
     ts.setMonitor(ts.printMonitor)
@@ -67,6 +79,8 @@ def main(*args):
         tseries.set_dt(float(v['dt']))
         save, closer = ts.makeSaveMonitor(tseries)
         ts.setMonitor(save)
+    if cl.check:
+        ts.setMonitor(ts.checkpointMonitor, (cl.check,))
     try:
         ts.solve()
     finally:

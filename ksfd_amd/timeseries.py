@@ -95,3 +95,16 @@ class TimeSeries:
             self.tsFile.close()
         else:
             self._flush_npz()
+
+
+def read_last(basename, size=1, rank=0):
+    """Last stored point of a series written by this module: (k, t, data[(dof,nx,ny[,nz])], info dict).
+    Counterpart of what resume_values reads through KSFD.TimeSeries (ksfdsolver2.py:525-578)."""
+    fn = '%ss%dr%d.npz' % (basename, size, rank)
+    if not os.path.exists(fn):
+        raise FileNotFoundError(fn + ' (only the .npz backend can be resumed from in this image: no h5py)')
+    z = np.load(fn)
+    ks, ts = z['ks'], z['times']
+    i = int(np.argmax(ts))
+    info = {k[5:]: z[k][()] for k in z.files if k.startswith('info_')}
+    return int(ks[i]), float(ts[i]), z['data%d' % int(ks[i])], info, (ts, ks)

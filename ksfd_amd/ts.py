@@ -255,9 +255,21 @@ class KSFDTS:
     def setFromOptions(self):
         pass
 
+    def _refresh_time_dependent_params(self):
+        """Parameters may be sympy expressions of t (ksfdsolver2.py:149-173); the reference hands ps.values(t) to its
+        ufuncs on every call.  Here the numeric table is re-sent once per step, evaluated at the step's start time."""
+        ps = self.derivs.ps
+        if not hasattr(ps, 'time_dependent') or not hasattr(ps, 'problem_config'):
+            return
+        if not hasattr(self, '_td'):
+            self._td = [k for k in ps.time_dependent() if k not in ('variance_timing_function', 't')]
+        if self._td:
+            self.ks.update_params(ps.problem_config(self._t))
+
     # ---- one TS.step(): replaces super().step() at KSFD/ksfdts.py:211
     def step(self):
         d = self.derivs
+        self._refresh_time_dependent_params()
         if d.has_sources():
             # time-dependent sources need the stage times t + ASum_i*h of THIS attempt: one attempt per call
             asum = (0.0, 8.7173304301691801e-01, 8.4457060015369423e-01 - 1.1299064236484185e-01, 1.0)
@@ -391,6 +403,15 @@ class KSFDTS:
 
     def historyMonitor(self, ts, k, t, u):
         self.history.append(dict(step=k, h=ts.getTimeStep(), t=t, u=u.array.copy()))
+
+    def checkpointMonitor(self, ts, k, t, u, prefix, mpiok=False):
+        """One single-point series per step, <prefix>_<k>_s<size>r<rank> (KSFD/ksfdts.py:370-451; no zip option)."""
+        from .timeseries import TimeSeries
+        cpf = TimeSeries(prefix + '_' + str(k) + '_', self.derivs.grid, mode='w')
+        cpf.set_dt(float(ts.getTimeStep()))
+        cpf.info['lastvart'] = float(getattr(self, 'lastvart', t))
+        cpf.store(u, t, k=k)
+        cpf.close()
 
     def makeSaveMonitor(self, timeseries):
         self.timeseries = timeseries

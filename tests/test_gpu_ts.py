@@ -107,3 +107,52 @@ def test_noise_injection_and_conserve_worms():
     corr = np.log(ratio) - sd * z                         # = log of the uniform conserve_worms correction
     assert np.ptp(corr) < 1e-12 and abs(corr.mean()) < 1e-3
     assert np.array_equal(noisy[3][2][1], plain[3][2][1])  # U untouched
+
+
+def test_resume_continues_a_saved_run(tmp_path):
+    """--save then --resume (ksfdsolver2.py:525-578): the resumed run starts from the stored state, time and dt"""
+    from ksfd_amd import solver
+    def optfile(maxsteps, keep_dt=True):
+        txt = open(os.path.join(GOLDEN, 'options', 'ks2d_two_ligands.txt')).read().replace('maxsteps=25', 'maxsteps=%d' % maxsteps)
+        if not keep_dt:            # an explicit dt= parameter overrides the stored one (ksfdsolver2.py:546-549)
+            txt = txt.replace('dt=1e-8\n', '')
+        f = tmp_path / ('opts%d.txt' % maxsteps)
+        f.write_text(txt)
+        return '@' + str(f)
+
+    p1 = str(tmp_path / 'a' / 'run')
+    ts1 = solver.main('ksfd', optfile(12), '--save=' + p1, '--check=' + str(tmp_path / 'cp' / 'c'))
+    t1, h1, u1 = ts1.getTime(), ts1.getTimeStep(), ts1.ks.get_state()
+    ts1.cleanup()
+    assert os.path.exists(str(tmp_path / 'cp' / 'c') + '_12_s1r0.npz')          # checkpointMonitor: one file per step
+    p2 = str(tmp_path / 'b' / 'run')
+    ts2 = solver.main('ksfd', optfile(5, keep_dt=False), '--resume=' + p1, '--save=' + p2)
+    z = np.load(p2 + 's1r0.npz')
+    assert abs(z['times'][0] - t1) < 1e-15 and np.array_equal(cijk_to_soa(z['data0']), u1)
+    assert abs(z['times'][1] - (t1 + h1)) < 1e-12 * max(1, t1)                 # first resumed step uses the stored dt
+    assert ts2.getStepNumber() == 5 and ts2.getTime() > t1
+    ts2.cleanup()
+
+
+def test_time_dependent_parameter_is_resent_each_step():
+    from ksfd_amd.ts import Derivatives, implicitTS
+    ns = opt.parse_commandline(['dim=1', 'nelements=64', 'width=0.05', 'sigma=0.02357', 's2=sigma**2/2*(1+10*t)',
+                                'alpha_1=1500', 'beta_1=5.56e-4', 's_1_1=0.01', 'gamma_1_1=0.01', 'D_1_1=1e-6',
+                                'dt=0.01', 'maxsteps=3', 'atol=0.01', 'rtol=1e-6', '--petsc', '-ts_adapt_type', 'none', '--'])
+    ps = opt.Params(ns)
+    cfg = ps.problem_config()
+    d = Derivatives(ps, cfg)
+    rho = 9000 + 90 * np.random.default_rng(0).standard_normal(64)
+    u0 = np.concatenate([rho, rho])
+    d.ks.set_state(u0)
+    ts = implicitTS(d, t0=0.0, dt=0.01, tmax=1.0, maxsteps=3, rtol=1e-6, atol=0.01, opts=opt.step_opts_from(ps, ns.petsc))
+    ts.opts.ksp_rtol = 1e-12
+    ts.solve()
+    got = d.ks.get_state()
+    ts.cleanup()
+    # the same three steps with the oracle, s2 evaluated at each step's start time
+    from oracle import ko
+    u = u0
+    for k in range(3):
+        u, _, _, _ = ko.Oracle(ps.problem_config(0.01 * k)).rosw_step(u, 0.01, 0.01, 1e-6, solver='lu')
+    assert rel_l2(got, u) < 1e-10
