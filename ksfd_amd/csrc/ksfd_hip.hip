@@ -53,6 +53,9 @@ struct ksfd_handle {
     int rank = 0, size = 1, device = 0;
     int64_t slow0 = 0;               // first owned global slow index
     hipStream_t st = nullptr;
+    hipStream_t st_comm = nullptr;            // halo exchange stream (overlapped with interior rows)
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+    bool overlap = true;
     Transport *tr = nullptr;
     std::string err;
 
@@ -274,6 +277,8 @@ static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
     S.nstrips = (int)((h->G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
     S.yseg = jvp ? h->yseg_jvp : h->yseg;
     S.nseg = (int)((h->G.sloc + S.yseg - 1) / S.yseg);
+    S.seg0 = 0;
+    S.seg_stride = 1;
     long long waves = (long long)S.nstrips * S.nseg;
     long long nb = (waves + 3) / 4;
     nb = (nb + 7) / 8 * 8;
@@ -378,6 +383,50 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
         // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// Jacobian action with the halo exchange of v hidden behind the interior rows (slab ranks, 2-D fused kernel):
+//   compute stream: [interior segments]                      [two boundary segments]
+//   comm stream   :   wait(v ready) -> ghost rows of v <- ring neighbours -> signal
+// Interior segments read owned rows only; the first and last segment are the only readers of ghost rows.
+static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift, double *out)
+{
+    int rc;
+    const KGeom &G = h->G;
+    if (h->size == 1) return op_jvp_frozen(h, v, mode, shift, out);
+    KStrips K = make_strips(h, true);
+    if (!h->overlap || !fused_ok(h) || K.nseg < 3 || h->P.nlig > 4) {
+        if ((rc = halo(h, v))) return rc;
+        return op_jvp_frozen(h, v, mode, shift, out);
+    }
+    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F;
+    const int nseg_total = K.nseg;
+    HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
+    {
+        KStrips Ki = K;
+        Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = nseg_total - 2;
+        long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
+        Ki.nblocks = (int)((nb + 7) / 8 * 8);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * (double)Ki.nseg / nseg_total);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Ki.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Ki, (const double *)h->coef, (const double *)v, mode, shift, out));
+    }
+    HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
+    {
+        Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * G.F * (double)G.inner * 2.0);
+        if (h->tr->exchange(v, G.F, G.plane, G.inner, G.sloc, G.ng, h->st_comm)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    }
+    HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
+    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
+    {
+        KStrips Kb = K;
+        Kb.seg0 = 0; Kb.seg_stride = nseg_total - 1; Kb.nseg = 2;
+        long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
+        Kb.nblocks = (int)((nb + 7) / 8 * 8);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * 2.0 / nseg_total);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Kb.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Kb, (const double *)h->coef, (const double *)v, mode, shift, out));
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -516,6 +565,9 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     for (auto e : h->pool) hipEventDestroy(e);
     mg_free(h);
     delete h->tr;
+    if (h->ev_ready) hipEventDestroy(h->ev_ready);
+    if (h->ev_halo) hipEventDestroy(h->ev_halo);
+    if (h->st_comm) hipStreamDestroy(h->st_comm);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -546,6 +598,9 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
 #define CFAIL(code, ...) do { int rc_ = fail(nullptr, code, __VA_ARGS__); ksfd_destroy(h); return rc_; } while (0)
     if (hipSetDevice(h->device) != hipSuccess) CFAIL(KSFD_EHIP, "hipSetDevice(%d) failed", h->device);
     if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) CFAIL(KSFD_EHIP, "hipStreamCreate failed");
+    if (h->size > 1 && (hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming) != hipSuccess)) CFAIL(KSFD_EHIP, "comm stream/event creation failed");
 
     KGeom &G = h->G;
     G.dim = cfg->dim; G.F = cfg->nlig + 1;
@@ -841,6 +896,7 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
         K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
         K.yseg = h->yseg_jvp;
         K.nseg = (int)((G.sloc + K.yseg - 1) / K.yseg);
+        K.seg0 = 0; K.seg_stride = 1;
         long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
         K.nblocks = (int)((nb + 7) / 8 * 8);
         Scope sc(h, cls, by);
@@ -1102,6 +1158,8 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
             if (use_pc) {
                 if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = apply_A(h->t1, w))) return rc;
+            } else if (h->use_frozen) {
+                if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
             const int k = j + 1;
             if (o->reserved == 1) {
@@ -1363,7 +1421,7 @@ extern "C" int ksfd_synchronize(ksfd_handle *h)
 extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, int32_t yseg_jvp)
 {
     if (!h) return KSFD_EINVAL;
-    if (use_fused >= 0) { h->use_fused = use_fused & 1; h->use_frozen = !(use_fused & 2); }
+    if (use_fused >= 0) { h->use_fused = use_fused & 1; h->use_frozen = !(use_fused & 2); h->overlap = !(use_fused & 4); }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;
     return KSFD_OK;

@@ -222,9 +222,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_velocity(KGeom G, KPhys P, const
 
 struct KStrips {
     int nstrips;      // ceil(nx / 124), strips balanced to even widths
-    int nseg;         // ceil(sloc / yseg)
+    int nseg;         // row segments handled by THIS launch
     int yseg;
     int nblocks;      // launch grid (multiple of 8 for the XCD remap)
+    int seg0;         // first segment and stride between the segments of this launch: the interior launch uses
+    int seg_stride;   // (1, 1), the boundary launch (0, nseg_total-1) = the two segments that read ghost rows
 };
 
 // blockIdx -> logical block so that each XCD (blocks are dealt round-robin over the 8 XCDs)
@@ -291,7 +293,7 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
     const long long wid = (long long)ksfd_xcd_remap(blockIdx.x, S.nblocks) * (KSFD_BLOCK / KSFD_WAVE) + (threadIdx.x >> 6);
     J.valid = wid < (long long)S.nstrips * S.nseg;
     const int strip = (int)(wid % S.nstrips);
-    const long long seg = wid / S.nstrips;
+    const long long seg = S.seg0 + (wid / S.nstrips) * S.seg_stride;
     const long long half = G.nx >> 1;
     const long long xs = 2 * ((long long)strip * half / S.nstrips);
     const long long xe = 2 * ((long long)(strip + 1) * half / S.nstrips);

@@ -87,7 +87,8 @@ def _run(size, shape, nlig, transport, tmp_path):
         assert np.allclose(z['got_' + k], z['ref_' + k], rtol=1e-9, atol=0), (k, z['got_' + k], z['ref_' + k])
 
 
-@pytest.mark.parametrize('size,shape,nlig', [(2, (64, 48), 1), (3, (40, 36), 2), (2, (16, 12, 16), 1), (2, (33, 16), 1)])
+@pytest.mark.parametrize('size,shape,nlig', [(2, (64, 48), 1), (3, (40, 36), 2), (2, (16, 12, 16), 1), (2, (33, 16), 1),
+                                             (2, (140, 160), 1), (3, (64, 240), 2)])   # last two: >= 3 row segments per rank -> halo/compute overlap path
 def test_slab_ranks_match_single_rank_host_transport(size, shape, nlig, tmp_path):
     _run(size, shape, nlig, 'host', tmp_path)
 
