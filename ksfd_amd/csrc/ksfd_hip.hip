@@ -77,7 +77,7 @@ struct ksfd_handle {
 
     // tuning
     int use_fused = 1;
-    int yseg = 32;        // rows per wave segment, RHS kernel (measured best at 4096^2)
+    int yseg = 35;        // rows per wave segment, RHS kernel (measured best at 4096^2)
     int yseg_jvp = 16;    // same for the Jacobian-action kernels
     int zseg = 32;        // planes per wave segment, 3-D z-marching kernel
 

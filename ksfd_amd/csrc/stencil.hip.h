@@ -285,6 +285,10 @@ struct KWaveJob {
     long long r0, r1;   // row segment [r0, r1)
     bool store;
     bool valid;
+    bool up;            // march direction.  Even segments go up, odd ones down, so two neighbouring segments read
+                        // their shared halo rows at the same time (one HBM fetch, one L2 hit) instead of a wave
+                        // lifetime apart.  All first y-derivatives enter as products of pairs: the sign cancels.
+    __device__ __forceinline__ long long row(long long q) const { return up ? q : (r0 + r1 - 1 - q); }
 };
 __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips &S)
 {
@@ -304,6 +308,7 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
     J.store = lane >= 1 && lane <= (int)((xe - xs) >> 1);
     J.r0 = seg * S.yseg;
     J.r1 = J.r0 + S.yseg < G.sloc ? J.r0 + S.yseg : G.sloc;
+    J.up = (seg & 1) == 0;
     return J;
 }
 
@@ -350,11 +355,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
     };
 
     // prologue: rows r0-2 .. r0+1 fill slots 1..4 after four pushes
-    for (int q = -2; q <= 1; q++) { load_row(J.r0 + q); push_row(); }
-    load_row(J.r0 + 2);
+    for (int q = -2; q <= 1; q++) { load_row(J.row(J.r0 + q)); push_row(); }
+    load_row(J.row(J.r0 + 2));
     for (long long r = J.r0; r < J.r1; r++) {
         push_row();                             // window now centred on row r
-        if (r + 1 < J.r1) load_row(r + 3);      // prefetch for the next iteration
+        if (r + 1 < J.r1) load_row(J.row(r + 3));      // prefetch for the next iteration
         // x neighbours of the centre row
         const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
         const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
             }
         }
         if (J.store) {
-            const long long pi = r * G.nx + J.c0;                 // dense interior index
+            const long long pi = J.row(r) * G.nx + J.c0;          // dense interior index
             const long long o = (long long)G.ng * G.inner + pi;   // offset inside a plane
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
@@ -442,11 +447,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_fused(KGeom G, KPhys P, KS
         }
     };
 
-    for (int q = -2; q <= 1; q++) { load_row(J.r0 + q); push_row(); }
-    load_row(J.r0 + 2);
+    for (int q = -2; q <= 1; q++) { load_row(J.row(J.r0 + q)); push_row(); }
+    load_row(J.row(J.r0 + 2));
     for (long long r = J.r0; r < J.r1; r++) {
         push_row();
-        if (r + 1 < J.r1) load_row(r + 3);
+        if (r + 1 < J.r1) load_row(J.row(r + 3));
         const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
         const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
         const KX xv = ksfd_xnb(vw[2][0], vw[2][1]);
@@ -486,7 +491,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_fused(KGeom G, KPhys P, KS
             }
         }
         if (J.store) {
-            const long long o = (long long)G.ng * G.inner + r * G.nx + J.c0;
+            const long long o = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
 #pragma unroll
             for (int c = 0; c <= NL; c++) ksfd_st2(out + (long long)c * G.plane + o, res[c][0], res[c][1]);
         }
@@ -577,11 +582,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         }
     };
 
-    for (int q = -2; q <= 1; q++) { load_row(J.r0 + q); push_row(); }
-    load_row(J.r0 + 2);
+    for (int q = -2; q <= 1; q++) { load_row(J.row(J.r0 + q)); push_row(); }
+    load_row(J.row(J.r0 + 2));
     for (long long r = J.r0; r < J.r1; r++) {
         push_row();
-        if (r + 1 < J.r1) load_row(r + 3);
+        if (r + 1 < J.r1) load_row(J.row(r + 3));
         const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
         const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
         const KX xv = ksfd_xnb(vw[2][0], vw[2][1]);
@@ -621,7 +626,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
             }
         }
         if (J.store) {
-            const long long o = (long long)G.ng * G.inner + r * G.nx + J.c0;
+            const long long o = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
@@ -674,6 +679,8 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
     if (c0 < 0) c0 += G.nx;
     const bool store = lane >= 1 && lane <= (int)((xe - xs) >> 1);
     const long long k0 = zs * S.zseg, k1 = k0 + S.zseg < G.sloc ? k0 + S.zseg : G.sloc;
+    const bool up = (zs & 1) == 0;                 // alternate marching direction: see KWaveJob::up
+    auto kmap = [&](long long q) { return up ? q : (k0 + k1 - 1 - q); };
     const long long rowc = y * G.nx + c0;
     long long yo[4];                                          // row offsets of y-2, y-1, y+1, y+2 (periodic)
     {
@@ -707,12 +714,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
             for (int l = 0; l < NL; l++) zw[l][4][e] = nz[l][e];
         }
     };
-    for (int q = -2; q <= 1; q++) { load_plane(k0 + q); push(); }
-    load_plane(k0 + 2);
+    for (int q = -2; q <= 1; q++) { load_plane(kmap(k0 + q)); push(); }
+    load_plane(kmap(k0 + 2));
     for (long long k = k0; k < k1; k++) {
         push();
-        if (k + 1 < k1) load_plane(k + 3);
-        const long long po = ksfd_planeoff(G, k);
+        if (k + 1 < k1) load_plane(kmap(k + 3));
+        const long long kc = kmap(k);
+        const long long po = ksfd_planeoff(G, kc);
         // y-neighbour rows of the centre plane
         double2 yr[4], yg[4], yv[4], ye[4];
 #pragma unroll
@@ -772,7 +780,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
 #undef KY
         }
         if (store) {
-            const long long o = (long long)G.ng * G.inner + k * G.nx * G.ny + rowc;
+            const long long o = (long long)G.ng * G.inner + kc * G.nx * G.ny + rowc;
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
