@@ -47,7 +47,7 @@ def lib():
         _LIB.ko_cfl.argtypes = [cp, dp, dp, dp]
         _LIB.ko_wrms.argtypes = [C.c_int64, dp, dp, C.c_double, C.c_double]
         _LIB.ko_wrms.restype = C.c_double
-        _LIB.ko_adapt_basic.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_int)] + [C.c_double] * 5
+        _LIB.ko_adapt_basic.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_int)] + [C.c_double] * 5 + [C.c_int, C.c_double]
         _LIB.ko_adapt_basic.restype = C.c_double
         _LIB.ko_tableau_get.argtypes = [dp] * 5
         _LIB.ko_rosw_step.argtypes = [cp, dp, C.c_double, C.POINTER(dp), C.c_double, C.c_double, C.c_int,
@@ -168,9 +168,10 @@ def wrms(unew, err, atol, rtol):
     return lib().ko_wrms(unew.size, _dp(unew), _dp(err), float(atol), float(rtol))
 
 
-def adapt_basic(h, enorm, safety=0.9, clip=(0.1, 5.0), dt_min=1e-20, dt_max=1e4):
+def adapt_basic(h, enorm, safety=0.9, clip=(0.1, 5.0), dt_min=1e-20, dt_max=1e4, prev_accept=True, reject_safety=0.5):
     acc = C.c_int()
-    hn = lib().ko_adapt_basic(float(h), float(enorm), C.byref(acc), safety, clip[0], clip[1], dt_min, dt_max)
+    hn = lib().ko_adapt_basic(float(h), float(enorm), C.byref(acc), safety, clip[0], clip[1], dt_min, dt_max,
+                              int(bool(prev_accept)), reject_safety)
     return hn, bool(acc.value)
 
 

@@ -336,11 +336,15 @@ double ko_wrms(int64_t n, const double *unew, const double *err, double atol, do
     return sqrt(s / (double)n);
 }
 
-/* TSAdaptChoose_Basic: accept iff enorm<=1; hfac = clip(safety*enorm^(-1/order)), order=3. */
+/* TSAdaptChoose_Basic (PETSc src/ts/adapt/impls/basic, restated): accept iff enorm<=1 (or h already at dt_min);
+ * hfac = clip(safety*enorm^(-1/order)), order=3; after two consecutive rejections safety *= reject_safety. */
 double ko_adapt_basic(double h, double enorm, int *accept, double safety, double clip_lo, double clip_hi,
-                      double dt_min, double dt_max)
+                      double dt_min, double dt_max, int prev_accept, double reject_safety)
 {
-    *accept = enorm <= 1.0;
+    if (enorm > 1.0) {
+        if (!prev_accept) safety *= reject_safety;
+        *accept = h < (1.0 + 1.4901161193847656e-08) * dt_min;
+    } else *accept = 1;
     double hfac = enorm > 0.0 ? safety * pow(enorm, -1.0 / 3.0) : INFINITY;
     if (hfac < clip_lo) hfac = clip_lo;
     if (hfac > clip_hi) hfac = clip_hi;

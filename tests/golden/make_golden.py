@@ -455,6 +455,84 @@ def step_3d_n1():
     step_case('step_3d_n1', 3, [8, 8, 8], [0.05, 0.05, 0.05], LIG_N1, 'tophat', 25, h=0.1, nsteps=3)
 
 
+def adaptive_case(name, dim, n, L, lig, cap, seed, nsteps, dt0=1e-8, atol=0.01, rtol=1e-6, amp=90.0, near_cap=False):
+    """TSAdaptBasic restated: accept iff wrms<=1; h_next = h*clip(safety*wrms^(-1/3), 0.1, 5), safety
+    0.9 (x0.5 after a rejection); reference operators + exact LU per attempt.  Records every accepted (t,h) and wrms."""
+    tt = time.time()
+    ps, g, d = build(dim, n, L, lig, cap)
+    F = ps.nligands + 1
+    S = g.Slshape
+    rng = np.random.default_rng(seed)
+    u = seeded_state(rng, F, S, amp=amp)
+    if near_cap:
+        u[0] = np.asfortranarray(23000.0 + 2500.0 * np.sin(2 * np.pi * g.coordsNoGhosts[0] / L[0]) *
+                                 np.cos(2 * np.pi * g.coordsNoGhosts[1] / L[1]) + amp * rng.standard_normal(S))
+    for l, lg in enumerate(ps.Vgroups.ligands()):
+        u[l + 1] = u[0] * float(lg.s / lg.gamma)
+    out = meta_of(ps, g, cap)
+    out['u0'] = u.copy()
+    out['dt0'], out['atol'], out['rtol'] = np.float64(dt0), np.float64(atol), np.float64(rtol)
+    t, h = 0.0, dt0
+    ts, hs, wr, rejs = [], [], [], []
+    for k in range(nsteps):
+        prev_accept, nrej = True, 0
+        while True:
+            unew, err, w = rosw_step(d, u, t, h, atol, rtol)
+            safety = 0.9
+            accept = w <= 1.0
+            if not accept and not prev_accept:
+                safety *= 0.5
+            hfac = min(max(safety * w ** (-1.0 / 3.0), 0.1), 5.0) if w > 0 else 5.0
+            hnext = min(max(h * hfac, 1e-20), 1e4)
+            prev_accept = accept
+            if accept:
+                u, t = unew, t + h
+                ts.append(t); hs.append(h); wr.append(w); rejs.append(nrej)
+                h = hnext
+                break
+            nrej += 1
+            h = hnext
+    out['uN'] = u
+    out['t_acc'], out['h_acc'], out['wrms'], out['rej'] = np.array(ts), np.array(hs), np.array(wr), np.array(rejs)
+    out['h_next'] = np.float64(h)
+    out['nsteps'] = np.int64(nsteps)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('%-24s F=%d shape=%s steps=%d t_end=%.4g h_end=%.3g rejections=%d  %.1fs' %
+          (name, F, S, nsteps, t, h, int(np.sum(rejs)), time.time() - tt), flush=True)
+
+
+@case
+def adapt_2d_n1():
+    adaptive_case('adapt_2d_n1', 2, [16, 16], [0.04, 0.04], LIG_N1, 'tophat', 31, nsteps=24)
+
+
+@case
+def adapt_2d_n1_reject():
+    # first trial step far too large: several consecutive rejections (reject_safety path), then recovery
+    adaptive_case('adapt_2d_n1_reject', 2, [16, 16], [0.04, 0.04], LIG_N1, 'tophat', 33, nsteps=10, dt0=2.0)
+
+
+@case
+def adapt_2d_n2_witch_cap():
+    adaptive_case('adapt_2d_n2_witch_cap', 2, [16, 12], [0.05, 0.04], LIG_N2, 'witch', 32, nsteps=16, near_cap=True)
+
+
+@case
+def step_2d_n1_witch_cap():
+    # rho up to ~rhomax: the cap potential's tanh is active in G, G_rho
+    def u0(g):
+        rng = np.random.default_rng(41)
+        x, y = g.coordsNoGhosts[0], g.coordsNoGhosts[1]
+        rho = 24000.0 + 3500.0 * np.sin(2 * np.pi * x / 0.05) * np.cos(2 * np.pi * y / 0.05) + 9 * rng.standard_normal(g.Slshape)
+        return np.asfortranarray(np.stack([rho, rho]))
+    step_case('step_2d_n1_witch_cap', 2, [16, 16], [0.05, 0.05], LIG_N1, 'witch', 41, h=0.002, nsteps=5, u0_fn=u0)
+
+
+@case
+def step_2d_g2():
+    step_case('step_2d_g2', 2, [12, 16], [0.04, 0.05], LIG_G2, 'tophat', 42, h=0.1, nsteps=4)
+
+
 @case
 def step_1d_manufactured():
     src, extra = manufactured_source()

@@ -175,3 +175,23 @@ def test_long_adaptive_run_reaches_large_steps():
     u = k.get_state()
     assert np.isfinite(u).all() and u.min() > 0
     k.close()
+
+
+@pytest.mark.parametrize('name', golden_cases('adapt_'))
+def test_adaptive_sequence_vs_reference_lu_golden(name):
+    """ksfd_step's own reject/accept loop reproduces the adaptive run of 'reference operators + exact LU +
+    TSAdaptBasic restated': same rejections, same accepted step sizes, same final state."""
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    k = klib.KSFDHip(cfg)
+    k.set_state(cijk_to_soa(z['u0']))
+    opts = klib.default_step_opts(adapt=1, atol=float(z['atol']), rtol=float(z['rtol']), ksp_rtol=1e-12, ksp_max_it=4000)
+    t, h = 0.0, float(z['dt0'])
+    for s in range(int(z['nsteps'])):
+        t, h, st, rc = k.step(t, h, opts)
+        assert st.accepted and st.rejections == z['rej'][s]
+        assert abs(st.h_used - z['h_acc'][s]) <= 1e-7 * z['h_acc'][s]
+        assert abs(t - z['t_acc'][s]) <= 1e-9 * max(t, 1e-30)
+    assert abs(h - float(z['h_next'])) <= 1e-6 * h
+    assert rel_l2(k.get_state(), cijk_to_soa(z['uN'])) < 1e-9
+    k.close()

@@ -86,3 +86,30 @@ def test_tableau_order_conditions():
     assert abs(b2 @ beta - 0.5) < 1e-14
     assert np.allclose((A + G)[3], b)          # stiffly accurate
     assert np.allclose(asum, alpha) and abs(gam - 4.3586652150845900e-01) < 1e-16
+
+
+@pytest.mark.parametrize('name', golden_cases('adapt_'))
+def test_oracle_adaptive_sequence_vs_reference_lu_golden(name):
+    """reject/accept decisions, step sizes and states of an adaptive run from dt0=1e-8 (TSAdaptBasic restated)"""
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    o = ko.Oracle(cfg)
+    u = cijk_to_soa(z['u0'])
+    t, h = 0.0, float(z['dt0'])
+    atol, rtol = float(z['atol']), float(z['rtol'])
+    for k in range(int(z['nsteps'])):
+        prev, nrej = True, 0
+        while True:
+            un, err, wr, _ = o.rosw_step(u, h, atol, rtol, solver='lu')
+            hn, acc = ko.adapt_basic(h, wr, prev_accept=prev)
+            prev = acc
+            if acc:
+                break
+            nrej += 1
+            h = hn
+        assert nrej == z['rej'][k]
+        assert abs(h - z['h_acc'][k]) <= 1e-9 * z['h_acc'][k]
+        assert abs(wr - z['wrms'][k]) <= 1e-6 * z['wrms'][k] + 1e-12
+        u, t, h = un, t + h, hn
+    assert abs(t - z['t_acc'][-1]) <= 1e-9 * t
+    assert rel_l2(u, cijk_to_soa(z['uN'])) < 1e-10
