@@ -1,10 +1,13 @@
 """TimeSeries writer fed from the device state (row (f)2 of SURVEY.md section 8: "next", not hot path).
 
-Schema follows KSFD/ksfdtimeseries.py (file <prefix>s<size>r<rank>.h5; /grid/* attributes :253-262;
-data<k> float64 (dof,nx,ny[,nz]) C order with attrs k,t :484-509; /times, /ks; /info/dt, /info/lastvart).
-h5py is NOT installed in this image, so the HDF5 branch below could not be exercised here; without h5py the
-same logical content goes to <prefix>s<size>r<rank>.npz (keys data<k>, t<k>, times, ks, grid_*, info_*), which
-is what the tests read back.  The /info dill blobs of the reference (ksfdtsmaker.py:10-29) are not written.
+Schema = KSFD/ksfdtimeseries.py: file <prefix>s<size>r<rank>.h5 (:188-243); root datasets size, rank, ranges, times,
+order, ks, lastk (:122-138, :378-391); /grid/<attr> datasets (:253-262); data<k> float64 (dof,nx,ny[,nz]) C order with
+attributes k, t (:484-509); /info/dt, /info/lastvart.  The file is flushed after every store so a crash leaves it
+valid (the reference closes and reopens it per step for the same reason, ksfdts.py:481-495).
+h5py is not installed in this image: the HDF5 backend goes through libhdf5 directly (ksfd_amd/h5lite.py); if libhdf5
+is not found either, the same logical content is written to <prefix>s<size>r<rank>.npz.
+Not written: the /info dill blobs (commandlineArguments, SolutionParameters, sources; ksfdtsmaker.py:10-29) -- they
+pickle the reference's own classes.
 """
 import os
 
@@ -12,10 +15,25 @@ import numpy as np
 
 from .layout import HDF5
 
-try:                                    # pragma: no cover - absent in this image
-    import h5py
-except ImportError:                     # noqa: D401
-    h5py = None
+try:
+    from . import h5lite
+    h5lite.lib()
+    HAVE_H5 = True
+except (ImportError, OSError):
+    HAVE_H5 = False
+
+GRID_ATTRS = ('dim', 'dof', 'nps', 'bounds', 'spacing', 'order', 'stencil_width', 'stencil_type', 'boundary_type',
+              'globalSshape', 'globalVshape', 'Slshape', 'Vlshape', 'ranges')
+
+
+def _grid_value(grid, a):
+    if a == 'order':
+        return getattr(grid, a, 3)
+    if a == 'stencil_type':
+        return getattr(grid, a, 0)           # DMDA STAR
+    if a == 'boundary_type':
+        return getattr(grid, a, 3)           # DM_BOUNDARY_PERIODIC
+    return getattr(grid, a)
 
 
 class TimeSeries:
@@ -23,58 +41,66 @@ class TimeSeries:
         self.grid = grid
         self.rank = getattr(getattr(grid, 'comm', None), 'rank', 0)
         self.size = getattr(getattr(grid, 'comm', None), 'size', 1)
-        self.backend = backend or ('h5' if h5py is not None else 'npz')
+        self.backend = backend or ('h5' if HAVE_H5 else 'npz')
         self.filename = '%ss%dr%d.%s' % (basename, self.size, self.rank, self.backend)
-        d = os.path.dirname(os.path.abspath(self.filename))
-        os.makedirs(d, exist_ok=True)
+        os.makedirs(os.path.dirname(os.path.abspath(self.filename)), exist_ok=True)
         self.ks, self.ts = [], []
         self.info = {}
         self.lastk = -1
         self._data = {}
         self.tsFile = None
-        if self.backend == 'h5':        # pragma: no cover
-            self.tsFile = h5py.File(self.filename, mode)
-            g = self.tsFile.require_group('grid')
-            for a in ('dim', 'dof', 'nps', 'bounds', 'spacing', 'stencil_width', 'globalSshape', 'globalVshape',
-                      'Slshape', 'Vlshape', 'ranges'):
-                g[a] = np.asarray(getattr(grid, a))
-            self.tsFile.require_group('info')
+        if self.backend == 'h5':
+            f = self.tsFile = h5lite.File(self.filename, mode)
+            f.require_group('/info')
+            f.write('/size', self.size)
+            f.write('/rank', self.rank)
+            f.write('/ranges', np.asarray(grid.ranges))
+            for a in GRID_ATTRS:
+                f.write('/grid/' + a, np.asarray(_grid_value(grid, a)))
+            f.flush()
 
     def store(self, data, t, k=None):
         """data: Vec-like with .array in PETSc layout, a DeviceVec, or an ndarray in PETSc layout."""
         ks = getattr(data, '_ks', None)
         if ks is not None:
-            C = ks.get_state(HDF5).reshape(self.grid.Vlshape)          # device -> (dof,nx,ny[,nz]) C order directly
+            Cv = ks.get_state(HDF5).reshape(self.grid.Vlshape)         # device -> (dof,nx,ny[,nz]) C order directly
         else:
             a = np.asarray(getattr(data, 'array', data))
-            C = np.ascontiguousarray(a.reshape(self.grid.Vlshape, order='F'))
+            Cv = np.ascontiguousarray(a.reshape(self.grid.Vlshape, order='F'))
         if k is None:
             k = self.lastk + 1
         self.lastk = k
-        self.ks.append(k)
-        self.ts.append(t)
-        if self.backend == 'h5':        # pragma: no cover
-            ds = self.tsFile.require_dataset('data%d' % k, self.grid.Vlshape, dtype=C.dtype)
-            ds.write_direct(C)
-            ds.attrs['k'] = k
-            ds.attrs['t'] = t
+        self.ks.append(int(k))
+        self.ts.append(float(t))
+        if self.backend == 'h5':
+            self.tsFile.write('/data%d' % k, Cv, attrs={'k': int(k), 't': float(t)})
+            self._write_index()
             self.tsFile.flush()
         else:
-            self._data['data%d' % k] = C
+            self._data['data%d' % k] = Cv
             self._data['t%d' % k] = np.float64(t)
             self._flush_npz()
+
+    def _write_index(self):
+        f = self.tsFile
+        ts = np.array(self.ts)
+        f.write('/times', ts)
+        f.write('/order', np.argsort(ts))
+        f.write('/ks', np.array(self.ks))
+        f.write('/lastk', self.lastk)
+        for key, v in self.info.items():
+            f.write('/info/' + key, v)
 
     def set_dt(self, h):
         self.info['dt'] = float(h)
 
     def _flush_npz(self):
         g = self.grid
-        meta = {('grid_' + a): np.asarray(getattr(g, a)) for a in
-                ('dim', 'dof', 'nps', 'bounds', 'spacing', 'stencil_width', 'globalVshape', 'Vlshape', 'ranges')}
+        meta = {('grid_' + a): np.asarray(_grid_value(g, a)) for a in GRID_ATTRS}
         meta.update({('info_' + k): np.asarray(v) for k, v in self.info.items()})
         tmp = self.filename + '.tmp.npz'
         np.savez(tmp, times=np.array(self.ts), ks=np.array(self.ks), **meta, **self._data)
-        os.replace(tmp, self.filename)          # the file is valid after every step (ksfdts.py:481-495 rationale)
+        os.replace(tmp, self.filename)
 
     def temp_close(self):
         pass
@@ -85,26 +111,49 @@ class TimeSeries:
     def flush(self):
         if self.backend == 'npz':
             self._flush_npz()
+        elif self.tsFile:
+            self._write_index()
+            self.tsFile.flush()
 
     def close(self):
-        if self.backend == 'h5':        # pragma: no cover
-            self.tsFile['times'] = np.array(self.ts)
-            self.tsFile['ks'] = np.array(self.ks)
-            for k, v in self.info.items():
-                self.tsFile['info'][k] = v
-            self.tsFile.close()
+        if self.backend == 'h5':
+            if self.tsFile:
+                self._write_index()
+                self.tsFile.close()
+                self.tsFile = None
         else:
             self._flush_npz()
 
 
 def read_last(basename, size=1, rank=0):
-    """Last stored point of a series written by this module: (k, t, data[(dof,nx,ny[,nz])], info dict).
+    """Last stored point of a series written by this module: (k, t, data[(dof,nx,ny[,nz])], info dict, (times, ks)).
     Counterpart of what resume_values reads through KSFD.TimeSeries (ksfdsolver2.py:525-578)."""
-    fn = '%ss%dr%d.npz' % (basename, size, rank)
-    if not os.path.exists(fn):
-        raise FileNotFoundError(fn + ' (only the .npz backend can be resumed from in this image: no h5py)')
-    z = np.load(fn)
-    ks, ts = z['ks'], z['times']
-    i = int(np.argmax(ts))
-    info = {k[5:]: z[k][()] for k in z.files if k.startswith('info_')}
-    return int(ks[i]), float(ts[i]), z['data%d' % int(ks[i])], info, (ts, ks)
+    stem = '%ss%dr%d' % (basename, size, rank)
+    if os.path.exists(stem + '.h5') and HAVE_H5:
+        f = h5lite.File(stem + '.h5', 'r')
+        ts, ks = f.read('/times'), f.read('/ks')
+        i = int(np.argmax(ts))
+        data = f.read('/data%d' % int(ks[i]))
+        info = {k: float(np.asarray(f.read('/info/' + k)).reshape(-1)[0]) for k in ('dt', 'lastvart') if f.exists('/info/' + k)}
+        f.close()
+        return int(ks[i]), float(ts[i]), data, info, (ts, ks)
+    if os.path.exists(stem + '.npz'):
+        z = np.load(stem + '.npz')
+        ks, ts = z['ks'], z['times']
+        i = int(np.argmax(ts))
+        info = {k[5:]: z[k][()] for k in z.files if k.startswith('info_')}
+        return int(ks[i]), float(ts[i]), z['data%d' % int(ks[i])], info, (ts, ks)
+    raise FileNotFoundError(stem + '.h5/.npz')
+
+
+def read_series(basename, size=1, rank=0):
+    """All points of a series written by this module: dict(times, ks, data={k: array})."""
+    stem = '%ss%dr%d' % (basename, size, rank)
+    if os.path.exists(stem + '.h5') and HAVE_H5:
+        f = h5lite.File(stem + '.h5', 'r')
+        ts, ks = f.read('/times'), f.read('/ks')
+        out = dict(times=ts, ks=ks, data={int(k): f.read('/data%d' % int(k)) for k in ks})
+        f.close()
+        return out
+    z = np.load(stem + '.npz')
+    return dict(times=z['times'], ks=z['ks'], data={int(k): z['data%d' % int(k)] for k in z['ks']})

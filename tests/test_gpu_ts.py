@@ -20,14 +20,15 @@ def test_solver_main_runs_options_file_with_monitors(tmp_path, capsys):
     lines = [l for l in out.splitlines() if l.startswith('clock:')]
     assert len(lines) == 26 and ' step  25 ' in lines[-1] and 'CFL=' in lines[-1]       # printMonitor format, ksfdts.py:337-353
     assert ts.getTimeStep() > 1e-4                   # TSAdaptBasic ramped up from dt=1e-8 (x5 per step at first)
-    z = np.load(prefix + 's1r0.npz')
-    assert list(z['ks']) == list(range(26)) and z['data25'].shape == (3, 48, 48)
+    from ksfd_amd.timeseries import read_series
+    z = read_series(prefix)
+    assert list(z['ks']) == list(range(26)) and z['data'][25].shape == (3, 48, 48)
     assert abs(z['times'][-1] - ts.getTime()) < 1e-15
     # the stored (dof,nx,ny) C-order dataset is the device state
     u = petsc_to_cijk(ts.getSolution().array, 3, (48, 48))
-    assert np.array_equal(z['data25'], u)
-    # worms are conserved by the scheme to rounding (periodic box, divergence form discretised consistently)
-    assert abs(u[0].sum() - z['data0'][0].sum()) < 1e-6 * z['data0'][0].sum()
+    assert np.array_equal(z['data'][25], u)
+    # total worms drift only at the 1e-6 level (the flux is discretised in non-conservative form, as in the reference)
+    assert abs(u[0].sum() - z['data'][0][0].sum()) < 1e-6 * z['data'][0][0].sum()
     ts.cleanup()
 
 
@@ -124,11 +125,13 @@ def test_resume_continues_a_saved_run(tmp_path):
     ts1 = solver.main('ksfd', optfile(12), '--save=' + p1, '--check=' + str(tmp_path / 'cp' / 'c'))
     t1, h1, u1 = ts1.getTime(), ts1.getTimeStep(), ts1.ks.get_state()
     ts1.cleanup()
-    assert os.path.exists(str(tmp_path / 'cp' / 'c') + '_12_s1r0.npz')          # checkpointMonitor: one file per step
+    import glob
+    assert glob.glob(str(tmp_path / 'cp' / 'c') + '_12_s1r0.*')                   # checkpointMonitor: one file per step
     p2 = str(tmp_path / 'b' / 'run')
     ts2 = solver.main('ksfd', optfile(5, keep_dt=False), '--resume=' + p1, '--save=' + p2)
-    z = np.load(p2 + 's1r0.npz')
-    assert abs(z['times'][0] - t1) < 1e-15 and np.array_equal(cijk_to_soa(z['data0']), u1)
+    from ksfd_amd.timeseries import read_series
+    z = read_series(p2)
+    assert abs(z['times'][0] - t1) < 1e-15 and np.array_equal(cijk_to_soa(z['data'][0]), u1)
     assert abs(z['times'][1] - (t1 + h1)) < 1e-12 * max(1, t1)                 # first resumed step uses the stored dt
     assert ts2.getStepNumber() == 5 and ts2.getTime() > t1
     ts2.cleanup()

@@ -1,0 +1,60 @@
+"""CPU: the TimeSeries writer (schema of KSFD/ksfdtimeseries.py) -- HDF5 through libhdf5/ctypes, read back with
+this module and, when the image's conda python has h5py, with h5py as an independent reader."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ksfd_amd.config import ProblemConfig
+from ksfd_amd.layout import cijk_to_petsc
+from ksfd_amd.timeseries import HAVE_H5, TimeSeries, read_last
+from ksfd_amd.ts import HostVec, LocalGrid
+
+CONDA_PY = '/opt/conda/bin/python3.9'
+
+
+def _series(tmp_path, backend):
+    cfg = ProblemConfig.standard(2, (12, 10), L=(1.0, 0.8), nlig=2)
+    grid = LocalGrid(cfg, (0, 10))
+    rng = np.random.default_rng(0)
+    ts = TimeSeries(str(tmp_path / 'out' / 'ser'), grid, mode='w', backend=backend)
+    states = []
+    for k, t in enumerate((0.0, 0.5, 1.25)):
+        u = rng.standard_normal((3, 12, 10))                # indexed [c, i, j]
+        states.append(u)
+        ts.set_dt(0.1 * (k + 1))
+        ts.store(HostVec(cijk_to_petsc(u)), t, k=k)          # what a monitor hands over: PETSc dof-fastest buffer
+    ts.close()
+    return ts, states
+
+
+@pytest.mark.parametrize('backend', ['h5', 'npz'])
+def test_store_and_read_last(tmp_path, backend):
+    if backend == 'h5' and not HAVE_H5:
+        pytest.skip('libhdf5 not found')
+    ts, states = _series(tmp_path, backend)
+    assert ts.filename.endswith('ser' + 's1r0.' + backend)
+    k, t, data, info, (times, ks) = read_last(str(tmp_path / 'out' / 'ser'))
+    assert (k, t) == (2, 1.25) and list(ks) == [0, 1, 2] and list(times) == [0.0, 0.5, 1.25]
+    assert np.array_equal(data, states[2]) and abs(info['dt'] - 0.3) < 1e-15
+
+
+@pytest.mark.skipif(not (HAVE_H5 and os.path.exists(CONDA_PY)), reason='needs libhdf5 and the conda h5py')
+def test_hdf5_file_is_readable_by_h5py_with_reference_schema(tmp_path):
+    ts, states = _series(tmp_path, 'h5')
+    np.save(tmp_path / 'want.npy', states[1])
+    code = '''
+import h5py, numpy as np, sys
+f = h5py.File(sys.argv[1], "r")
+assert set(["size", "rank", "ranges", "times", "order", "ks", "lastk", "grid", "info", "data0", "data1", "data2"]) <= set(f.keys())
+assert f["data1"].shape == (3, 12, 10) and f["data1"].dtype == np.float64
+assert f["data1"].attrs["k"] == 1 and f["data1"].attrs["t"] == 0.5
+assert np.array_equal(f["data1"][()], np.load(sys.argv[2]))
+assert list(f["times"][()]) == [0.0, 0.5, 1.25] and list(f["ks"][()]) == [0, 1, 2] and f["lastk"][()] == 2
+assert f["grid/dim"][()] == 2 and f["grid/dof"][()] == 3 and tuple(f["grid/Vlshape"][()]) == (3, 12, 10)
+assert abs(f["info/dt"][()] - 0.3) < 1e-15 and np.allclose(f["grid/spacing"][()], [1.0 / 12, 0.08])
+print("h5py-ok")
+'''
+    r = subprocess.run([CONDA_PY, '-c', code, ts.filename, str(tmp_path / 'want.npy')], capture_output=True, text=True)
+    assert 'h5py-ok' in r.stdout, r.stderr
