@@ -170,7 +170,8 @@ int ksfd_synchronize(ksfd_handle *h);
 /* raw kernel benchmark used by bench.py/profiles: run `reps` launches of one kernel class on the state,
  * timed with HIP events on the compute stream; returns average ms per launch. */
 int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms, double *bytes_per_launch);
-/* use_fused: bit0 fused kernels, bit1 set = recompute (non-frozen) Jacobian action, bit2 set = no halo/compute overlap;
+/* use_fused: bit0 fused kernels, bit1 set = recompute (non-frozen) Jacobian action, bit2 set = no halo/compute overlap,
+ * bit3 set = pipelined GMRES with device-resident Hessenberg/Givens state (off by default);
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

@@ -88,6 +88,13 @@ struct ksfd_handle {
     ksfd_profile prof;
     double bytes_acc = 0.0;
 
+    // pipelined GMRES (device-resident Hessenberg / Givens state, see gmres_async)
+    double *gm_dev = nullptr;       // [G (m+1)^2 | H (m+1)m | cs m | sn m | g m+1 | coef MAXDOT | scale 1 | mon 2(m+1)]
+    double *gm_host = nullptr;      // pinned: [mon 2(m+1) | H (m+1)m | g m+1]
+    std::vector<hipEvent_t> gm_ev;
+    int async_mode = 0;             // 0 off (default: measured no gain on one GPU, tools/async_bench.py), 1 whenever legal,
+                                    // 2 when the local problem is small
+
     // multigrid preconditioner
     std::vector<MGLevel> mg;
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
@@ -276,6 +283,14 @@ static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
     KStrips S;
     S.nstrips = (int)((h->G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
     S.yseg = jvp ? h->yseg_jvp : h->yseg;
+    // small grids: shorter segments so that there are enough waves to fill 256 CUs (a wave costs ~1 us per row it
+    // marches; the 4 halo rows per segment are L2 hits at these sizes)
+    {
+        const long long target = jvp ? 4096 : 6144;
+        long long fit = (long long)S.nstrips * h->G.sloc / target;
+        if (fit < 2) fit = 2;
+        if (fit < S.yseg) S.yseg = (int)fit;
+    }
     S.nseg = (int)((h->G.sloc + S.yseg - 1) / S.yseg);
     S.seg0 = 0;
     S.seg_stride = 1;
@@ -368,6 +383,11 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
         K.nygrp = (int)((G.ny + 3) / 4);
         K.zseg = h->zseg;
+        {
+            long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // blocks of 4 waves
+            if (fit < 2) fit = 2;
+            if (fit < K.zseg) K.zseg = (int)fit;
+        }
         K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
         long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
         K.nblocks = (int)((nb3 + 7) / 8 * 8);
@@ -561,6 +581,9 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     for (double *b : bufs) if (b) hipFree(b);
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
     if (h->hres) hipHostFree(h->hres);
+    if (h->gm_host) hipHostFree(h->gm_host);
+    if (h->gm_dev) hipFree(h->gm_dev);
+    for (auto e : h->gm_ev) if (e) hipEventDestroy(e);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
     mg_free(h);
@@ -637,6 +660,15 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     hipMemsetAsync(h->Y, 0, sizeof(double) * (size_t)(4 * h->vlen), h->st);
     hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)((h->restart_alloc + 1) * h->vlen), h->st);
     if (hipHostMalloc((void **)&h->hres, sizeof(double) * 128, hipHostMallocDefault) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
+    {
+        const int m = h->restart_alloc;
+        const size_t ndev = (size_t)(m + 1) * (m + 1) + (size_t)(m + 1) * m + 2 * m + (m + 1) + KSFD_MAXDOT + 1 + 2 * (m + 1);
+        const size_t nhost = 2 * (m + 1) + (size_t)(m + 1) * m + (m + 1);
+        if (alloc_d(h, &h->gm_dev, (int64_t)ndev)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
+        if (hipHostMalloc((void **)&h->gm_host, sizeof(double) * nhost, hipHostMallocDefault) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
+        h->gm_ev.resize(m + 1);
+        for (auto &e : h->gm_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) CFAIL(KSFD_EHIP, "hipEventCreate failed");
+    }
 
     if (h->size > 1) {
         std::string terr;
@@ -895,6 +927,11 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
         KStrips K;
         K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
         K.yseg = h->yseg_jvp;
+        {
+            long long fit = (long long)K.nstrips * G.sloc / 4096;
+            if (fit < 2) fit = 2;
+            if (fit < K.yseg) K.yseg = (int)fit;
+        }
         K.nseg = (int)((G.sloc + K.yseg - 1) / K.yseg);
         K.seg0 = 0; K.seg_stride = 1;
         long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
@@ -1249,6 +1286,123 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pipelined GMRES: same mathematics as gmres() (CGS2 with the algebraic second projection), but the small
+// algebra of every iteration runs in a one-thread kernel on the device (k_gmres_coef) and the fused update reads its
+// coefficients from device memory, so an iteration = [J action, multi-dot, reduce(+allreduce), coef, update] with NO
+// host round trip.  The host polls the residual estimate one iteration behind (and exactly on time when the
+// extrapolated estimate says "this one converges"), so the GPU never idles and at most one iteration is wasted.
+// Pays when an iteration is latency-bound: small grids, many slab ranks.  Unpreconditioned, frozen Jacobian only.
+// ------------------------------------------------------------------------------------------------
+static int gmres_async(ksfd_handle *h, double shift, const double *b, double *x, const ksfd_step_opts *o, LinStats *ls)
+{
+    const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
+    const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
+    const int64_t vs = h->vlen;
+    const int ld = h->restart_alloc + 1;
+    double *V = h->V;
+    double *dG = h->gm_dev, *dH = dG + (size_t)ld * ld, *dcs = dH + (size_t)ld * h->restart_alloc, *dsn = dcs + h->restart_alloc,
+           *dg = dsn + h->restart_alloc, *dcoef = dg + ld, *dscale = dcoef + KSFD_MAXDOT, *dmon = dscale + 1;
+    double *hmon = h->gm_host, *hH = hmon + 2 * ld, *hg = hH + (size_t)ld * h->restart_alloc;
+    int rc;
+    if ((rc = op_multidot(h, b, V, 0))) return rc;
+    const double bn = sqrt(h->hres[0]);
+    ls->its = 0; ls->rel = 0.0;
+    if (!(bn > 0.0)) {
+        if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
+        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
+        return KSFD_OK;
+    }
+    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
+    double beta = bn, rn = bn;
+    int total = 0;
+    bool first = true;
+    std::vector<double> y(m);
+    while (true) {
+        if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
+        else {
+            if ((rc = op_jvp_frozen_halo(h, x, 1, shift, V))) return rc;
+            const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
+            if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;
+            if ((rc = op_multidot(h, V, V, 0))) return rc;
+            beta = sqrt(h->hres[0]);
+            rn = beta;
+            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: residual is not finite");
+            if (beta <= tol) break;
+            const double *x1[1] = { V }; double a1[1] = { 1.0 / beta };
+            if ((rc = op_lincomb(h, 1, x1, a1, V))) return rc;
+        }
+        int jc = -1, jlast = -1, checked = -1;
+        double r1 = beta, r2 = -1.0;
+        auto poll = [&](int upto) -> int {          // read monitors (checked, upto]; sets jc when converged
+            for (int q = checked + 1; q <= upto; q++) {
+                if (hipEventSynchronize(h->gm_ev[q]) != hipSuccess) return fail(h, KSFD_EHIP, "event sync failed");
+                const double r = hmon[2 * q], hn = hmon[2 * q + 1];
+                if (!(r == r)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+                checked = q;
+                r2 = r1; r1 = r;
+                if (r <= tol || hn == 0.0) { jc = q; return KSFD_OK; }
+            }
+            return KSFD_OK;
+        };
+        for (int j = 0; j < m && total + j < maxit; j++) {
+            double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
+            const int k = j + 1;
+            if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
+            const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
+            {
+                Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
+                if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+                else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+                else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+                else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+            }
+            {
+                Scope sc(h, KC_REDUCE, 8.0 * (2 * k + 1) * (double)nb);
+                hipLaunchKernelGGL(k_reduce_rows, dim3(2 * k + 1), dim3(KSFD_BLOCK), 0, h->st, (const double *)h->part, nb, 0, h->dres);
+            }
+            if (h->size > 1 && h->tr->allreduce(h->dres, 2 * k + 1, 0, h->st)) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
+            hipLaunchKernelGGL(k_gmres_coef, dim3(1), dim3(64), 0, h->st, j, h->restart_alloc, beta, (const double *)h->dres, dG, dH, dcs, dsn, dg, dcoef, dscale, dmon);
+            {
+                Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
+                if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+                else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+                else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+                else VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+            }
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(hmon + 2 * j, dmon + 2 * j, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+            HIPCHK(h, hipEventRecord(h->gm_ev[j], h->st));
+            jlast = j;
+            if ((rc = poll(j - 1))) return rc;                 // one iteration behind: the GPU already has iteration j queued
+            if (jc >= 0) break;
+            if (r2 > 0.0 && r1 * (r1 / r2) <= 1.5 * tol) {     // extrapolation says iteration j converges: look now, queue nothing more
+                if ((rc = poll(j))) return rc;
+                if (jc >= 0) break;
+            }
+        }
+        if (jc < 0 && (rc = poll(jlast))) return rc;
+        const int kused = jc >= 0 ? jc + 1 : jlast + 1;
+        total += jlast + 1;
+        HIPCHK(h, hipMemcpyAsync(hH, dH, sizeof(double) * (size_t)ld * h->restart_alloc, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(h, hipMemcpyAsync(hg, dg, sizeof(double) * ld, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(h, hipStreamSynchronize(h->st));
+        for (int i = kused - 1; i >= 0; i--) {
+            double s = hg[i];
+            for (int q = i + 1; q < kused; q++) s -= hH[(size_t)ld * q + i] * y[q];
+            y[i] = s / hH[(size_t)ld * i + i];
+        }
+        if ((rc = op_basis_axpy(h, x, V, kused, y.data(), first ? 0.0 : 1.0))) return rc;
+        first = false;
+        rn = hmon[2 * (kused - 1)];
+        if (jc >= 0 || total >= maxit) break;
+    }
+    ls->its = total;
+    ls->rel = rn / bn;
+    if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 extern "C" void ksfd_default_step_opts(ksfd_step_opts *o)
 {
     memset(o, 0, sizeof *o);
@@ -1288,13 +1442,17 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
         // stiffness estimate h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~8
-        bool use_pc = false;
-        if (h->mg_ok && h->use_frozen && opts->pc_type) {
-            double dmax = h->P.s2, lap = 0.0;
-            for (int l = 0; l < h->P.nlig; l++) dmax = std::max(dmax, h->P.lig_D[l]);
-            for (int a = 0; a < h->G.dim; a++) lap += (16.0 / 3.0) * h->P.inv_h2[a];
-            use_pc = opts->pc_type == 1 || (dmax * lap / shift > 8.0);
-        }
+        double dmax = h->P.s2, lap = 0.0;
+        for (int l = 0; l < h->P.nlig; l++) dmax = std::max(dmax, h->P.lig_D[l]);
+        for (int a = 0; a < h->G.dim; a++) lap += (16.0 / 3.0) * h->P.inv_h2[a];
+        const double stiff = dmax * lap / shift;
+        const bool use_pc = h->mg_ok && h->use_frozen && opts->pc_type && (opts->pc_type == 1 || stiff > 8.0);
+        // pipelined solver: latency-bound iterations only (small local problem), not in the tiny-h regime where the
+        // Pythagorean norm update cancels heavily (|w|^2/h_n^2 ~ 1/stiff^2) and gmres() takes its explicit second pass
+        const bool small = (double)h->G.F * (double)h->G.nloc <= 6.0e6;
+        const bool use_async = !use_pc && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
+                               (h->size == 1 || h->tr->device_allreduce()) &&
+                               (h->async_mode == 1 || (h->async_mode == 2 && small));
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
             if (i > 0) {
@@ -1315,7 +1473,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 if (nt > 1 && (rc = op_lincomb(h, nt, xs, a, h->bvec))) break;
             }
             LinStats ls;
-            rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc);
+            rc = use_async ? gmres_async(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls)
+                           : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc);
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
         }
@@ -1421,7 +1580,10 @@ extern "C" int ksfd_synchronize(ksfd_handle *h)
 extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, int32_t yseg_jvp)
 {
     if (!h) return KSFD_EINVAL;
-    if (use_fused >= 0) { h->use_fused = use_fused & 1; h->use_frozen = !(use_fused & 2); h->overlap = !(use_fused & 4); }
+    if (use_fused >= 0) {
+        h->use_fused = use_fused & 1; h->use_frozen = !(use_fused & 2); h->overlap = !(use_fused & 4);
+        h->async_mode = (use_fused & 8) ? 1 : 0;
+    }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;
     return KSFD_OK;

@@ -393,3 +393,87 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_to_host_layout(KGeom G, int layo
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride)
         flat[ksfd_host_index(G, layout, c, p)] = dev[(long long)c * devplane + devoff + p];
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident small algebra of one GMRES iteration (pipelined solver, gmres_async in ksfd_hip.hip):
+// from the reduced dots of iteration j (k = j+1 basis vectors):  d = V^T w, Gram row g = V^T v_j, ww = |w|^2
+//   c = d + (I - G) d ,  hn^2 = ww - 2 c.d + c.G c     (CGS2 with the second projection done algebraically)
+//   Hessenberg column [c; hn] -> previous Givens rotations -> new rotation -> residual estimate |g_{j+1}|
+// Outputs: coef[0..k) and scale = 1/hn for the fused update kernel, mon[2j] = residual estimate, mon[2j+1] = hn.
+// One thread: k <= 32, i.e. < 3k FMAs.
+__global__ void k_gmres_coef(int j, int m, double beta, const double *__restrict__ dres, double *__restrict__ Gm,
+                             double *__restrict__ H, double *__restrict__ cs, double *__restrict__ sn,
+                             double *__restrict__ g, double *__restrict__ coef, double *__restrict__ scale,
+                             double *__restrict__ mon)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int k = j + 1, ld = m + 1;
+    if (j == 0) { for (int i = 0; i <= m; i++) g[i] = 0.0; g[0] = beta; }
+    const double *d = dres, *gr = dres + k;
+    const double ww = dres[2 * k];
+    for (int i = 0; i < k; i++) { Gm[i * ld + j] = gr[i]; Gm[j * ld + i] = gr[i]; }
+    double c[KSFD_MAXDOT];
+    double cd = 0.0, cGc = 0.0;
+    for (int i = 0; i < k; i++) {
+        double s = 0.0;
+        for (int l = 0; l < k; l++) s += ((i == l ? 1.0 : 0.0) - Gm[i * ld + l]) * d[l];
+        c[i] = d[i] + s;
+    }
+    for (int i = 0; i < k; i++) {
+        cd += c[i] * d[i];
+        double s = 0.0;
+        for (int l = 0; l < k; l++) s += Gm[i * ld + l] * c[l];
+        cGc += c[i] * s;
+    }
+    double hn2 = ww - 2.0 * cd + cGc;
+    if (!(hn2 > 0.0)) hn2 = (hn2 != hn2) ? hn2 : 0.0;       // keep NaN visible, clamp negatives
+    const double hn = sqrt(hn2);
+    for (int i = 0; i < k; i++) coef[i] = c[i];
+    *scale = hn > 0.0 ? 1.0 / hn : 0.0;
+    double *Hc = H + (size_t)ld * j;
+    for (int i = 0; i < k; i++) Hc[i] = c[i];
+    Hc[k] = hn;
+    for (int i = 0; i < j; i++) {
+        const double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1];
+        Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1];
+        Hc[i] = t;
+    }
+    const double den = hypot(Hc[j], Hc[j + 1]);
+    cs[j] = den > 0.0 ? Hc[j] / den : 1.0;
+    sn[j] = den > 0.0 ? Hc[j + 1] / den : 0.0;
+    Hc[j] = den;
+    Hc[j + 1] = 0.0;
+    g[j + 1] = -sn[j] * g[j];
+    g[j] = cs[j] * g[j];
+    mon[2 * j] = fabs(g[j + 1]);
+    mon[2 * j + 1] = hn;
+}
+
+// w = (w - sum_{i<k} coef[i] V_i) * (*scale), coefficients read from device memory
+template <int KMAX, int VW>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_gs_update_dev(KVec g, double *__restrict__ w,
+                                                              const double *__restrict__ V, long long vstride, int k,
+                                                              const double *__restrict__ coef,
+                                                              const double *__restrict__ scale)
+{
+    const long long base = (long long)blockIdx.y * g.plane + g.off;
+    const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    double cf[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) cf[i] = i < k ? coef[i] : 0.0;
+    const double sc = *scale;
+    for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
+        typename KPack<VW>::T s = kload<VW>(w + base + p);
+#pragma unroll
+        for (int i = 0; i < KMAX; i++)
+            if (i < k) {
+                const typename KPack<VW>::T vv = kload<VW>(V + (long long)i * vstride + base + p);
+#pragma unroll
+                for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) - cf[i] * kget(vv, e));
+            }
+#pragma unroll
+        for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) * sc);
+        kstore<VW>(w + base + p, s);
+    }
+}

@@ -21,6 +21,7 @@ struct Transport {
     virtual int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) = 0;
     virtual int allreduce(double *dev, int n, int op, hipStream_t st) = 0;   // op 0 sum, 1 max; in place
     virtual bool result_on_host() const { return false; }
+    virtual bool device_allreduce() const { return true; }   // allreduce is stream-ordered and leaves the result on the device
     virtual const double *host_result() const { return nullptr; }
     const std::string &error() const { return err; }
     std::string err;
@@ -138,6 +139,7 @@ struct CallbackTransport : Transport {
         return 0;
     }
     bool result_on_host() const override { return true; }
+    bool device_allreduce() const override { return false; }
     const double *host_result() const override { return hred; }
 };
 
