@@ -1027,41 +1027,51 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
 // Chebyshev smoothing of A x = b on level L with Dinv; nu sweeps; eigen-interval [lmax/ratio, lmax]
 static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, double *x, int nu, bool zero_init, double ratio)
 {
+    // Chebyshev iteration in the "direction" form:  d_0 = Dinv r_0 / theta ; x += d_k ; r -= A d_k ;
+    // d_{k+1} = c1 d_k + c2 Dinv r.   nu sweeps = nu updates of x = nu-1 operator applications (+1 for a nonzero guess).
+    // Fusions: a zero guess writes x = d_0 directly; the last sweep folds "x += d_old + d_new" into one kernel.
     int rc;
     const int F = L.G.F;
     const int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     const double lmax = L.lam_max, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig1 = theta / delta;
     const double *res = b;
-    if (zero_init) {
-        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)L.vlen, h->st));
-    } else {
+    if (!zero_init) {
         if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;        // r = b - A x
         res = L.r;
     }
     {
-        Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, res, 1.0 / theta, L.d));
+        Scope sc(h, KC_MG, 8.0 * ((zero_init ? 3 : 2) * F + F * F) * L.G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, res, 1.0 / theta, L.d, zero_init ? x : (double *)nullptr));
     }
-    if (zero_init && nu > 1) HIPCHK(h, hipMemcpyAsync(L.r, b, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
+    bool x_has_d = zero_init;          // x == d_0 already
     double rho = 1.0 / sig1;
-    for (int k = 1; k <= nu; k++) {
-        if (k == nu) {
-            // x += d only
-            const double *xs[2] = { x, L.d };
-            KLin LL;
-            for (int t = 0; t < 6; t++) { LL.x[t] = t < 2 ? xs[t] : nullptr; LL.a[t] = t < 2 ? 1.0 : 0.0; }
-            Scope sc(h, KC_MG, 24.0 * L.vlen);
-            hipLaunchKernelGGL((k_lincomb<2, 1>), dim3(L.nblk, F), dim3(KSFD_BLOCK), 0, h->st, L.kv, LL, x);
-            break;
-        }
+    for (int k = 1; k < nu; k++) {
         if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
         const double rhon = 1.0 / (2.0 * sig1 - rho);
-        {
+        const double *rsrc = (zero_init && k == 1) ? b : L.r;             // first sweep from a zero guess: r_0 = b, never copied
+        if (k == nu - 1) {
+            Scope sc(h, KC_MG, 8.0 * (5 * F + F * F) * L.G.nloc);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_last<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, x, rsrc, (const double *)L.d, (const double *)L.Ad, rhon * rho, 2.0 * rhon / delta, x_has_d ? 1 : 0));
+            x_has_d = true;
+        } else {
+            if (rsrc != L.r) HIPCHK(h, hipMemcpyAsync(L.r, b, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
+            if (x_has_d && k == 1) { /* x already holds d_0: the step kernel adds d to x, so undo by starting x at 0 */
+                HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)L.vlen, h->st));
+            }
             Scope sc(h, KC_MG, 8.0 * (7 * F + F * F) * L.G.nloc);
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, x, L.r, L.d, (const double *)L.Ad, rhon * rho, 2.0 * rhon / delta));
+            x_has_d = false;
         }
         rho = rhon;
+    }
+    if (!x_has_d) {
+        // x += d (only reached when nu == 1 with a nonzero guess, or after k_cheb_step sweeps)
+        const double *xs[2] = { x, L.d };
+        KLin LL;
+        for (int t = 0; t < 6; t++) { LL.x[t] = t < 2 ? xs[t] : nullptr; LL.a[t] = t < 2 ? 1.0 : 0.0; }
+        Scope sc(h, KC_MG, 24.0 * L.vlen);
+        hipLaunchKernelGGL((k_lincomb<2, 1>), dim3(L.nblk, F), dim3(KSFD_BLOCK), 0, h->st, L.kv, LL, x);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;

@@ -106,10 +106,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, 
     }
 }
 
-// z = scale * Dinv r
+// z = scale * Dinv r   (and z2 = the same values when z2 != NULL: first Chebyshev sweep from a zero guess, x = d)
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long long plane, const double *__restrict__ dinv,
-                                                           const double *__restrict__ r, double scale, double *__restrict__ z)
+                                                           const double *__restrict__ r, double scale, double *__restrict__ z,
+                                                           double *__restrict__ z2 = nullptr)
 {
     constexpr int F = NL + 1;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -123,6 +124,36 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long lon
 #pragma unroll
             for (int c = 0; c < F; c++) s += dinv[(long long)(a * F + c) * plane + p] * rv[c];
             z[(long long)a * plane + p] = scale * s;
+            if (z2) z2[(long long)a * plane + p] = scale * s;
+        }
+    }
+}
+
+// Last Chebyshev sweep: x += d_old + d_new with d_new = c1*d_old + c2*Dinv (r - Ad); r and d are dead afterwards.
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_last(long long n, long long plane, const double *__restrict__ dinv,
+                                                          double *__restrict__ x, const double *__restrict__ r,
+                                                          const double *__restrict__ d, const double *__restrict__ Ad,
+                                                          double c1, double c2, int x_has_d)
+{
+    constexpr int F = NL + 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double rv[F], dv[F];
+#pragma unroll
+        for (int c = 0; c < F; c++) {
+            const long long o = (long long)c * plane + p;
+            dv[c] = d[o];
+            rv[c] = r[o] - Ad[o];
+        }
+#pragma unroll
+        for (int a = 0; a < F; a++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < F; c++) s += dinv[(long long)(a * F + c) * plane + p] * rv[c];
+            const long long o = (long long)a * plane + p;
+            // x_has_d: x already contains d_old (zero-guess start wrote x = d)
+            x[o] += (x_has_d ? 0.0 : dv[a]) + c1 * dv[a] + c2 * s;
         }
     }
 }
