@@ -893,27 +893,44 @@ static void mg_free(ksfd_handle *h)
 
 static int mg_build(ksfd_handle *h)
 {
-    if (h->G.dim != 2 || h->size != 1) return KSFD_OK;
+    if (h->G.dim != 2) return KSFD_OK;
     int nl = h->P.nlig, F = h->G.F;
-    long long nx = h->G.nx, ny = h->G.ny;
+    long long nx = h->G.nx, rows = h->G.sloc;          // rows = local rows of this rank's slab
+    // NOTE: every decision below must be identical on all ranks (the levels exchange halos): use sloc, never slow0.
+    // Slab r starts at row r*sloc; it stays on the coarse grid of level l as long as sloc is divisible by 2^l.
     KPhys P = h->P;
     for (int l = 0;; l++) {
         MGLevel L;
-        L.G = h->G; L.G.nx = nx; L.G.ny = ny; L.G.inner = nx; L.G.sloc = ny; L.G.plane = nx * ny; L.G.nloc = nx * ny;
+        L.G = h->G; L.G.nx = nx; L.G.ny = rows; L.G.inner = nx; L.G.sloc = rows;
+        L.G.plane = (rows + 2 * L.G.ng) * nx; L.G.nloc = rows * nx;
         L.P = P;
-        L.kv.plane = L.G.plane; L.kv.off = 0; L.kv.nloc = L.G.nloc; L.kv.nf = F;
+        L.kv.plane = L.G.plane; L.kv.off = (long long)L.G.ng * nx; L.kv.nloc = L.G.nloc; L.kv.nf = F;
         L.vlen = (int64_t)F * L.G.plane;
         L.nblk = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
         if (l == 0) L.coef = h->coef;
         else if (alloc_d(h, &L.coef, (int64_t)(3 + nl) * L.G.plane) || alloc_d(h, &L.x, L.vlen) || alloc_d(h, &L.b, L.vlen)) return KSFD_ENOMEM;
         if (alloc_d(h, &L.dinv, (int64_t)F * F * L.G.plane) || alloc_d(h, &L.r, L.vlen) || alloc_d(h, &L.d, L.vlen) ||
             alloc_d(h, &L.Ad, L.vlen) || alloc_d(h, &L.dG, L.G.plane)) return KSFD_ENOMEM;
+        double *zero[] = { l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad };
+        for (double *z : zero) if (z) hipMemsetAsync(z, 0, sizeof(double) * (size_t)L.vlen, h->st);
         h->mg.push_back(L);
-        if ((nx % 2) || (ny % 2) || nx / 2 < 8 || ny / 2 < 8) break;
-        nx /= 2; ny /= 2;
+        // next level: every rank keeps >= 4 rows (ghost width 2 + the 4th-order star), global grid >= 8 per axis
+        const long long rows_glob = rows * h->size;
+        if ((nx % 2) || (rows % 2) || nx / 2 < 8 || rows_glob / 2 < 8 || (h->size > 1 && rows / 2 < 4)) break;
+        nx /= 2; rows /= 2;
         for (int a = 0; a < 3; a++) { P.inv_h[a] *= 0.5; P.inv_h2[a] *= 0.25; }
     }
     h->mg_ok = h->mg.size() >= 2;
+    if (h->size > 1) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
+    return KSFD_OK;
+}
+
+// ghost rows of a level vector (np field planes) from the ring neighbours
+static int mg_halo(ksfd_handle *h, MGLevel &L, double *v, int np)
+{
+    if (h->size == 1) return KSFD_OK;
+    Scope sc(h, KC_HALO, 4.0 * 8.0 * np * (double)L.G.inner * 2.0);
+    if (h->tr->exchange(v, np, L.G.plane, L.G.inner, L.G.sloc, L.G.ng, h->st)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
     return KSFD_OK;
 }
 
@@ -921,6 +938,7 @@ static int mg_build(ksfd_handle *h)
 static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double shift, double *out, const double *yadd)
 {
     const KGeom &G = L.G;
+    if (h->size > 1) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
     const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
     const double by = 8.0 * ((3 + h->P.nlig) + 2.0 * G.F + (mode == 2 ? G.F : 0)) * (double)G.nloc;
     if (h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
@@ -968,11 +986,16 @@ static int mg_norm(ksfd_handle *h, MGLevel &L, const double *v, double *nrm)
 static int mg_restrict_coefs(ksfd_handle *h)
 {
     const int np = 3 + h->P.nlig;
+    int rc;
     for (size_t l = 0; l + 1 < h->mg.size(); l++) {
         MGLevel &Lf = h->mg[l], &Lc = h->mg[l + 1];
         int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_MG, 8.0 * np * (Lf.G.nloc + Lc.G.nloc));
-        hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, (const double *)Lf.coef, Lf.G.plane, Lc.coef, Lc.G.plane);
+        {
+            Scope sc(h, KC_MG, 8.0 * np * (Lf.G.nloc + Lc.G.nloc));
+            hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
+                               (const double *)Lf.coef, Lf.G.plane, Lf.kv.off, Lc.coef, Lc.G.plane, Lc.kv.off);
+        }
+        if ((rc = mg_halo(h, Lc, Lc.coef, np))) return rc;       // fine ghosts were valid; now the coarse ones are too
     }
     HIPCHK(h, hipGetLastError());
     h->mg_coef_valid = true;
@@ -1000,7 +1023,7 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
             if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
             {
                 Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
-                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, (const double *)L.Ad, 1.0, L.r));
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0, L.r + L.kv.off));
             }
             double nw;
             if ((rc = mg_norm(h, L, L.r, &nw))) return rc;
@@ -1008,13 +1031,13 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
             lam = nw / nv;
             // v <- w / |w|
             Scope sc(h, KC_MG, 16.0 * L.vlen);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, (const double *)L.Ad, 1.0 / nw, L.d));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0 / nw, L.d + L.kv.off));
             nv = 1.0;
         }
         L.lam_max = 1.15 * lam;
         if (l + 1 == h->mg.size()) {
             int nbr = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 256);
-            hipLaunchKernelGGL(k_ratio_est, dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, (long long)L.G.nloc, (const double *)L.dinv, shift, h->part);
+            hipLaunchKernelGGL(k_ratio_est, dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, (long long)L.G.nloc, (const double *)(L.dinv + L.kv.off), shift, h->part);
             if ((rc = reduce_rows(h, 1, nbr, 1))) return rc;
             L.ratio = std::max(30.0, 1.5 * L.lam_max * h->hres[0]);
         }
@@ -1035,6 +1058,7 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
     const int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     const double lmax = L.lam_max, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig1 = theta / delta;
+    const long long off = L.kv.off;     // owned rows start here inside a (ghosted) plane
     const double *res = b;
     if (!zero_init) {
         if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;        // r = b - A x
@@ -1042,7 +1066,7 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
     }
     {
         Scope sc(h, KC_MG, 8.0 * ((zero_init ? 3 : 2) * F + F * F) * L.G.nloc);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, res, 1.0 / theta, L.d, zero_init ? x : (double *)nullptr));
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), res + off, 1.0 / theta, L.d + off, zero_init ? x + off : (double *)nullptr));
     }
     bool x_has_d = zero_init;          // x == d_0 already
     double rho = 1.0 / sig1;
@@ -1052,7 +1076,7 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
         const double *rsrc = (zero_init && k == 1) ? b : L.r;             // first sweep from a zero guess: r_0 = b, never copied
         if (k == nu - 1) {
             Scope sc(h, KC_MG, 8.0 * (5 * F + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_last<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, x, rsrc, (const double *)L.d, (const double *)L.Ad, rhon * rho, 2.0 * rhon / delta, x_has_d ? 1 : 0));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_last<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), x + off, rsrc + off, (const double *)(L.d + off), (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta, x_has_d ? 1 : 0));
             x_has_d = true;
         } else {
             if (rsrc != L.r) HIPCHK(h, hipMemcpyAsync(L.r, b, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
@@ -1060,7 +1084,7 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
                 HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)L.vlen, h->st));
             }
             Scope sc(h, KC_MG, 8.0 * (7 * F + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)L.dinv, x, L.r, L.d, (const double *)L.Ad, rhon * rho, 2.0 * rhon / delta));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), x + off, L.r + off, L.d + off, (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta));
             x_has_d = false;
         }
         rho = rhon;
@@ -1084,16 +1108,20 @@ static int mg_coarse_correction(ksfd_handle *h, size_t l, double shift, double *
 {
     int rc;
     MGLevel &L = h->mg[l], &Lc = h->mg[l + 1];
+    if ((rc = mg_halo(h, L, L.r, L.G.F))) return rc;                 // restriction reads fine rows -1 and sloc
     int nbc = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     {
         Scope sc(h, KC_MG, 8.0 * L.G.F * (L.G.nloc + Lc.G.nloc));
-        hipLaunchKernelGGL(k_restrict2d, dim3(nbc), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.ny, (const double *)L.r, L.G.plane, Lc.b, Lc.G.plane);
+        hipLaunchKernelGGL(k_restrict2d, dim3(nbc), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.sloc, L.G.wrap_slow,
+                           (const double *)L.r, L.G.plane, L.kv.off, Lc.b, Lc.G.plane, Lc.kv.off);
     }
     if ((rc = mg_vcycle(h, l + 1, shift, Lc.b, Lc.x))) return rc;
+    if ((rc = mg_halo(h, Lc, Lc.x, L.G.F))) return rc;               // prolongation reads coarse row sloc_c
     int nbf = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     {
         Scope sc(h, KC_MG, 8.0 * L.G.F * (2 * L.G.nloc + Lc.G.nloc));
-        hipLaunchKernelGGL(k_prolong_add2d, dim3(nbf), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.ny, (const double *)Lc.x, Lc.G.plane, x, L.G.plane);
+        hipLaunchKernelGGL(k_prolong_add2d, dim3(nbf), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.sloc, L.G.wrap_slow,
+                           (const double *)Lc.x, Lc.G.plane, Lc.kv.off, x, L.G.plane, L.kv.off);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -1204,7 +1232,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         for (; j < m && total < maxit; j++) {
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
             if (use_pc) {
-                if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = apply_A(h->t1, w))) return rc;
+                if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
             } else if (h->use_frozen) {
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;

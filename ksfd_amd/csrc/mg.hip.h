@@ -11,10 +11,12 @@
 #pragma once
 #include "stencil.hip.h"
 
-// coarse(I,J) = sum_{a,b in -1..1} w_a w_b fine(2I+a, 2J+b), w = (1/4, 1/2, 1/4); periodic.
-__global__ void __launch_bounds__(KSFD_BLOCK) k_restrict2d(int nplanes, long long nxf, long long nyf,
-                                                           const double *__restrict__ fine, long long fplane,
-                                                           double *__restrict__ coarse, long long cplane)
+// coarse(I,J) = sum_{a,b in -1..1} w_a w_b fine(2I+a, 2J+b), w = (1/4, 1/2, 1/4).  x is periodic; the row axis either
+// wraps (one rank) or reads the ghost rows at local index -1 / nyf (slab ranks: the fine vector's halo must be current
+// and the slab must start on an even global row).  foff/coff = offset of local row 0 inside a plane (ng*nx).
+__global__ void __launch_bounds__(KSFD_BLOCK) k_restrict2d(int nplanes, long long nxf, long long nyf, int wrap,
+                                                           const double *__restrict__ fine, long long fplane, long long foff,
+                                                           double *__restrict__ coarse, long long cplane, long long coff)
 {
     const long long nxc = nxf >> 1, nyc = nyf >> 1, nc = nxc * nyc;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -22,32 +24,33 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_restrict2d(int nplanes, long lon
         const long long I = p % nxc, J = p / nxc;
         const long long i0 = 2 * I, j0 = 2 * J;
         const long long im = (i0 + nxf - 1) % nxf, ip = (i0 + 1) % nxf;
-        const long long jm = (j0 + nyf - 1) % nyf, jp = (j0 + 1) % nyf;
+        const long long jm = wrap ? (j0 + nyf - 1) % nyf : j0 - 1, jp = wrap ? (j0 + 1) % nyf : j0 + 1;
         for (int c = 0; c < nplanes; c++) {
-            const double *f = fine + (long long)c * fplane;
+            const double *f = fine + (long long)c * fplane + foff;
             const double s = 0.25 * f[i0 + nxf * j0] +
                              0.125 * (f[im + nxf * j0] + f[ip + nxf * j0] + f[i0 + nxf * jm] + f[i0 + nxf * jp]) +
                              0.0625 * (f[im + nxf * jm] + f[ip + nxf * jm] + f[im + nxf * jp] + f[ip + nxf * jp]);
-            coarse[(long long)c * cplane + p] = s;
+            coarse[(long long)c * cplane + coff + p] = s;
         }
     }
 }
 
-// fine += P coarse (bilinear interpolation, periodic)
-__global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long long nxf, long long nyf,
-                                                              const double *__restrict__ coarse, long long cplane,
-                                                              double *__restrict__ fine, long long fplane)
+// fine += P coarse (bilinear interpolation); row axis wraps or reads the coarse ghost row nyc (slab ranks)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long long nxf, long long nyf, int wrap,
+                                                              const double *__restrict__ coarse, long long cplane, long long coff,
+                                                              double *__restrict__ fine, long long fplane, long long foff)
 {
     const long long nxc = nxf >> 1, nyc = nyf >> 1, nf = nxf * nyf;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nf; p += stride) {
         const long long i = p % nxf, j = p / nxf;
         const long long I = i >> 1, J = j >> 1;
-        const long long I1 = (i & 1) ? (I + 1) % nxc : I, J1 = (j & 1) ? (J + 1) % nyc : J;
+        const long long I1 = (i & 1) ? (I + 1) % nxc : I;
+        const long long J1 = (j & 1) ? (wrap ? (J + 1) % nyc : J + 1) : J;
         for (int c = 0; c < nplanes; c++) {
-            const double *q = coarse + (long long)c * cplane;
+            const double *q = coarse + (long long)c * cplane + coff;
             const double v = 0.25 * (q[I + nxc * J] + q[I1 + nxc * J] + q[I + nxc * J1] + q[I1 + nxc * J1]);
-            fine[(long long)c * fplane + p] += v;
+            fine[(long long)c * fplane + foff + p] += v;
         }
     }
 }
@@ -72,7 +75,8 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, 
             KNbr n = ksfd_nbr(G, a, i, j, k);
             lapG += KSFD_D2(Gb[n.m2], Gb[n.m1], Gb[n.c], Gb[n.p1], Gb[n.p2]) * P.inv_h2[a];
         }
-        const double rho = C[p], gr = C[2 * G.plane + p];
+        const long long o = (long long)G.ng * G.inner + p;       // owned point inside a (ghosted) plane
+        const double rho = C[o], gr = C[2 * G.plane + o];
         double M[F][F], Inv[F][F];
 #pragma unroll
         for (int r = 0; r < F; r++)
@@ -81,7 +85,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, 
         M[0][0] = shift - (lapG + rho * gr * c2);
 #pragma unroll
         for (int l = 0; l < NL; l++) {
-            M[0][l + 1] = -rho * C[(long long)(3 + l) * G.plane + p] * c2;
+            M[0][l + 1] = -rho * C[(long long)(3 + l) * G.plane + o] * c2;
             M[l + 1][0] = -P.lig_s[l];
             M[l + 1][l + 1] = shift + P.lig_gamma[l] - P.lig_D[l] * c2;
         }
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, 
 #pragma unroll
         for (int r = 0; r < F; r++)
 #pragma unroll
-            for (int c = 0; c < F; c++) dinv[(long long)(r * F + c) * G.plane + p] = Inv[r][c];
+            for (int c = 0; c < F; c++) dinv[(long long)(r * F + c) * G.plane + o] = Inv[r][c];
     }
 }
 

@@ -109,7 +109,7 @@ struct CallbackTransport : Transport {
     {
         ex = d->exchange; ar = d->allreduce; ctx = d->ctx;
         if (!ex || !ar) { err = "transport 2 needs exchange and allreduce callbacks"; return false; }
-        chunk = (size_t)F * 2 * inner;
+        chunk = (size_t)(F + 2) * 2 * inner;                  // F fields (+2: the 3+n coefficient planes of a coarse level fit too)
         if (hipHostMalloc((void **)&stage, sizeof(double) * chunk * 4, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&hred, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return false; }
         return true;
@@ -118,13 +118,15 @@ struct CallbackTransport : Transport {
     int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) override
     {
         const size_t w = sizeof(double) * (size_t)ng * inner;     // bytes per field per side
+        const size_t cnt = (size_t)F * ng * inner;                // doubles per side in THIS call (coarse multigrid levels are smaller)
+        if (cnt > chunk) { err = "halo larger than the staging buffers"; return 1; }
         double *slo = stage, *shi = stage + chunk, *rlo = stage + 2 * chunk, *rhi = stage + 3 * chunk;
         hipError_t e;
         e = hipMemcpy2DAsync(slo, w, vec + (long long)ng * inner, sizeof(double) * plane, w, F, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpy2DAsync(shi, w, vec + sloc * inner, sizeof(double) * plane, w, F, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { err = std::string("halo D2H: ") + hipGetErrorString(e); return 1; }
-        if (ex(ctx, slo, shi, rlo, rhi, (int64_t)chunk)) { err = "exchange callback reported failure"; return 1; }
+        if (ex(ctx, slo, shi, rlo, rhi, (int64_t)cnt)) { err = "exchange callback reported failure"; return 1; }
         e = hipMemcpy2DAsync(vec, sizeof(double) * plane, rlo, w, w, F, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpy2DAsync(vec + (sloc + ng) * inner, sizeof(double) * plane, rhi, w, w, F, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { err = std::string("halo H2D: ") + hipGetErrorString(e); return 1; }

@@ -15,7 +15,7 @@ def worker(rank, size, port, transport):
     from ksfd_amd import lib as klib
     from ksfd_amd.config import ProblemConfig
     from ksfd_amd.dist import open_handle, local_slab, gather_slabs
-    cfg = ProblemConfig.standard(2, (64, 48), L=(0.2, 0.25), nlig=1)
+    cfg = ProblemConfig.standard(2, (64, 96), L=(0.2, 0.25), nlig=1)
     rng = np.random.default_rng(3); N = cfg.N
     rho = 9000 + 90 * rng.standard_normal(N)
     u = np.concatenate([rho, rho + rng.standard_normal(N)])
@@ -31,6 +31,9 @@ def worker(rank, size, port, transport):
     for i in range(3):
         t, h, st, rc = ks.step(t, h, opts, raise_on_error=False)
         log('step', i, t, h, st.accepted, st.rejections, st.linear_its, st.wrms, rc, ks.last_error() if rc else '')
+    stiff = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=1)
+    t, hh, st, rc = ks.step(t, 5.0, stiff, raise_on_error=False)
+    log('mg step', t, st.accepted, st.linear_its, st.wrms, rc, ks.last_error() if rc else '')
     ks.close(); log('closed')
     dist.destroy_process_group(); log('done')
 
