@@ -893,18 +893,21 @@ static void mg_free(ksfd_handle *h)
 
 static int mg_build(ksfd_handle *h)
 {
-    if (h->G.dim != 2) return KSFD_OK;
+    if (h->G.dim < 2) return KSFD_OK;
+    const int dim = h->G.dim;
     int nl = h->P.nlig, F = h->G.F;
-    long long nx = h->G.nx, rows = h->G.sloc;          // rows = local rows of this rank's slab
+    long long nx = h->G.nx, ny = dim == 3 ? h->G.ny : 1, rows = h->G.sloc;   // rows = local slow units (y rows in 2-D, z planes in 3-D)
     // NOTE: every decision below must be identical on all ranks (the levels exchange halos): use sloc, never slow0.
-    // Slab r starts at row r*sloc; it stays on the coarse grid of level l as long as sloc is divisible by 2^l.
+    // Slab r starts at unit r*sloc; it stays on the coarse grid of level l as long as sloc is divisible by 2^l.
     KPhys P = h->P;
     for (int l = 0;; l++) {
         MGLevel L;
-        L.G = h->G; L.G.nx = nx; L.G.ny = rows; L.G.inner = nx; L.G.sloc = rows;
-        L.G.plane = (rows + 2 * L.G.ng) * nx; L.G.nloc = rows * nx;
+        L.G = h->G; L.G.nx = nx;
+        if (dim == 2) { L.G.ny = rows; L.G.inner = nx; } else { L.G.ny = ny; L.G.nz = rows; L.G.inner = nx * ny; }
+        L.G.sloc = rows;
+        L.G.plane = (rows + 2 * L.G.ng) * L.G.inner; L.G.nloc = rows * L.G.inner;
         L.P = P;
-        L.kv.plane = L.G.plane; L.kv.off = (long long)L.G.ng * nx; L.kv.nloc = L.G.nloc; L.kv.nf = F;
+        L.kv.plane = L.G.plane; L.kv.off = (long long)L.G.ng * L.G.inner; L.kv.nloc = L.G.nloc; L.kv.nf = F;
         L.vlen = (int64_t)F * L.G.plane;
         L.nblk = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
         if (l == 0) L.coef = h->coef;
@@ -914,15 +917,39 @@ static int mg_build(ksfd_handle *h)
         double *zero[] = { l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad };
         for (double *z : zero) if (z) hipMemsetAsync(z, 0, sizeof(double) * (size_t)L.vlen, h->st);
         h->mg.push_back(L);
-        // next level: every rank keeps >= 4 rows (ghost width 2 + the 4th-order star), global grid >= 8 per axis
+        // next level: every rank keeps >= 4 slow units (ghost width 2 + the 4th-order star), global grid >= 8 per axis
         const long long rows_glob = rows * h->size;
         if ((nx % 2) || (rows % 2) || nx / 2 < 8 || rows_glob / 2 < 8 || (h->size > 1 && rows / 2 < 4)) break;
+        if (dim == 3 && ((ny % 2) || ny / 2 < 8)) break;
         nx /= 2; rows /= 2;
+        if (dim == 3) ny /= 2;
         for (int a = 0; a < 3; a++) { P.inv_h[a] *= 0.5; P.inv_h2[a] *= 0.25; }
     }
     h->mg_ok = h->mg.size() >= 2;
     if (h->size > 1) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
     return KSFD_OK;
+}
+
+// transfer operators, 2-D or 3-D by the level geometry
+static void mg_launch_restrict(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *fine, double *coarse)
+{
+    int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    if (Lf.G.dim == 3)
+        hipLaunchKernelGGL(k_restrict3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
+                           fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
+    else
+        hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
+                           fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
+}
+static void mg_launch_prolong(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *coarse, double *fine)
+{
+    int nb = (int)std::min<long long>((Lf.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    if (Lf.G.dim == 3)
+        hipLaunchKernelGGL(k_prolong_add3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
+                           coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
+    else
+        hipLaunchKernelGGL(k_prolong_add2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
+                           coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
 }
 
 // ghost rows of a level vector (np field planes) from the ring neighbours
@@ -941,7 +968,7 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
     if (h->size > 1) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
     const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
     const double by = 8.0 * ((3 + h->P.nlig) + 2.0 * G.F + (mode == 2 ? G.F : 0)) * (double)G.nloc;
-    if (h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
+    if (G.dim == 2 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
         KStrips K;
         K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
         K.yseg = h->yseg_jvp;
@@ -956,6 +983,23 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
         K.nblocks = (int)((nb + 7) / 8 * 8);
         Scope sc(h, cls, by);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd));
+    } else if (G.dim == 3 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        K3D K;
+        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+        K.nygrp = (int)((G.ny + 3) / 4);
+        K.zseg = h->zseg;
+        {
+            long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;
+            if (fit < 2) fit = 2;
+            if (fit < K.zseg) K.zseg = (int)fit;
+        }
+        K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
+        long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
+        K.nblocks = (int)((nb3 + 7) / 8 * 8);
+        Scope sc(h, cls, by + 8.0 * G.plane);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)L.coef, v, L.dG));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, (const double *)L.dG, mode, shift, out, yadd));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         Scope sc(h, cls, by + 8.0 * G.plane);
@@ -989,11 +1033,9 @@ static int mg_restrict_coefs(ksfd_handle *h)
     int rc;
     for (size_t l = 0; l + 1 < h->mg.size(); l++) {
         MGLevel &Lf = h->mg[l], &Lc = h->mg[l + 1];
-        int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
             Scope sc(h, KC_MG, 8.0 * np * (Lf.G.nloc + Lc.G.nloc));
-            hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
-                               (const double *)Lf.coef, Lf.G.plane, Lf.kv.off, Lc.coef, Lc.G.plane, Lc.kv.off);
+            mg_launch_restrict(h, Lf, Lc, np, Lf.coef, Lc.coef);
         }
         if ((rc = mg_halo(h, Lc, Lc.coef, np))) return rc;       // fine ghosts were valid; now the coarse ones are too
     }
@@ -1109,19 +1151,15 @@ static int mg_coarse_correction(ksfd_handle *h, size_t l, double shift, double *
     int rc;
     MGLevel &L = h->mg[l], &Lc = h->mg[l + 1];
     if ((rc = mg_halo(h, L, L.r, L.G.F))) return rc;                 // restriction reads fine rows -1 and sloc
-    int nbc = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     {
         Scope sc(h, KC_MG, 8.0 * L.G.F * (L.G.nloc + Lc.G.nloc));
-        hipLaunchKernelGGL(k_restrict2d, dim3(nbc), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.sloc, L.G.wrap_slow,
-                           (const double *)L.r, L.G.plane, L.kv.off, Lc.b, Lc.G.plane, Lc.kv.off);
+        mg_launch_restrict(h, L, Lc, L.G.F, L.r, Lc.b);
     }
     if ((rc = mg_vcycle(h, l + 1, shift, Lc.b, Lc.x))) return rc;
     if ((rc = mg_halo(h, Lc, Lc.x, L.G.F))) return rc;               // prolongation reads coarse row sloc_c
-    int nbf = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     {
         Scope sc(h, KC_MG, 8.0 * L.G.F * (2 * L.G.nloc + Lc.G.nloc));
-        hipLaunchKernelGGL(k_prolong_add2d, dim3(nbf), dim3(KSFD_BLOCK), 0, h->st, L.G.F, L.G.nx, L.G.sloc, L.G.wrap_slow,
-                           (const double *)Lc.x, Lc.G.plane, Lc.kv.off, x, L.G.plane, L.kv.off);
+        mg_launch_prolong(h, L, Lc, L.G.F, Lc.x, x);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;

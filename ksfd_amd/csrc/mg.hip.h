@@ -7,7 +7,7 @@
 // iteration preconditioned by the inverse of the point-block (F x F) diagonal of A_l.  Vertex-centred full
 // coarsening on the periodic box, full-weighting restriction, bilinear prolongation, V(nu,nu) cycle, fixed
 // polynomial smoothing on the coarsest grid -- every piece is a fixed linear operator, so plain
-// right-preconditioned GMRES applies.  2-D, single rank (round 1).
+// right-preconditioned GMRES applies.  2-D and 3-D, single rank or slab ranks.
 #pragma once
 #include "stencil.hip.h"
 
@@ -50,6 +50,56 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long 
         for (int c = 0; c < nplanes; c++) {
             const double *q = coarse + (long long)c * cplane + coff;
             const double v = 0.25 * (q[I + nxc * J] + q[I1 + nxc * J] + q[I + nxc * J1] + q[I1 + nxc * J1]);
+            fine[(long long)c * fplane + foff + p] += v;
+        }
+    }
+}
+
+// 3-D transfer operators (slab axis = z): 27-point full weighting and trilinear interpolation.  x and y wrap; z wraps
+// (one rank) or reads ghost planes -1 / nzf (slab ranks).  foff/coff = offset of local plane 0 inside a field plane.
+__global__ void __launch_bounds__(KSFD_BLOCK) k_restrict3d(int nplanes, long long nxf, long long nyf, long long nzf, int wrap,
+                                                           const double *__restrict__ fine, long long fplane, long long foff,
+                                                           double *__restrict__ coarse, long long cplane, long long coff)
+{
+    const long long nxc = nxf >> 1, nyc = nyf >> 1, nzc = nzf >> 1, nc = nxc * nyc * nzc;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nc; p += stride) {
+        const long long I = p % nxc, J = (p / nxc) % nyc, K = p / (nxc * nyc);
+        long long xi[3], yj[3], zk[3];
+        xi[1] = 2 * I; xi[0] = (xi[1] + nxf - 1) % nxf; xi[2] = (xi[1] + 1) % nxf;
+        yj[1] = 2 * J; yj[0] = (yj[1] + nyf - 1) % nyf; yj[2] = (yj[1] + 1) % nyf;
+        zk[1] = 2 * K; zk[0] = wrap ? (zk[1] + nzf - 1) % nzf : zk[1] - 1; zk[2] = wrap ? (zk[1] + 1) % nzf : zk[1] + 1;
+        const double w[3] = { 0.25, 0.5, 0.25 };
+        for (int c = 0; c < nplanes; c++) {
+            const double *f = fine + (long long)c * fplane + foff;
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+#pragma unroll
+                    for (int d = 0; d < 3; d++) s += w[a] * w[b] * w[d] * f[xi[d] + nxf * (yj[b] + nyf * zk[a])];
+            coarse[(long long)c * cplane + coff + p] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add3d(int nplanes, long long nxf, long long nyf, long long nzf, int wrap,
+                                                              const double *__restrict__ coarse, long long cplane, long long coff,
+                                                              double *__restrict__ fine, long long fplane, long long foff)
+{
+    const long long nxc = nxf >> 1, nyc = nyf >> 1, nzc = nzf >> 1, nf = nxf * nyf * nzf;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nf; p += stride) {
+        const long long i = p % nxf, j = (p / nxf) % nyf, k = p / (nxf * nyf);
+        const long long I = i >> 1, J = j >> 1, K = k >> 1;
+        const long long I1 = (i & 1) ? (I + 1) % nxc : I, J1 = (j & 1) ? (J + 1) % nyc : J;
+        const long long K1 = (k & 1) ? (wrap ? (K + 1) % nzc : K + 1) : K;
+        for (int c = 0; c < nplanes; c++) {
+            const double *q = coarse + (long long)c * cplane + coff;
+            const double v = 0.125 * (q[I + nxc * (J + nyc * K)] + q[I1 + nxc * (J + nyc * K)] + q[I + nxc * (J1 + nyc * K)] +
+                                      q[I1 + nxc * (J1 + nyc * K)] + q[I + nxc * (J + nyc * K1)] + q[I1 + nxc * (J + nyc * K1)] +
+                                      q[I + nxc * (J1 + nyc * K1)] + q[I1 + nxc * (J1 + nyc * K1)]);
             fine[(long long)c * fplane + foff + p] += v;
         }
     }

@@ -196,3 +196,21 @@ def test_adaptive_sequence_vs_reference_lu_golden(name):
     assert abs(h - float(z['h_next'])) <= 1e-6 * h
     assert rel_l2(k.get_state(), cijk_to_soa(z['uN'])) < 1e-9
     k.close()
+
+
+def test_multigrid_3d_stiff_step_vs_oracle_lu():
+    """3-D hierarchy (27-point full weighting / trilinear, z-marching Jacobian action on every level)"""
+    cfg = ProblemConfig.standard(3, (16, 16, 16), L=(0.04, 0.04, 0.04), nlig=1)
+    rng = np.random.default_rng(6)
+    N = 16 ** 3
+    rho = 9000 + 90 * rng.standard_normal(N)
+    u = np.concatenate([rho, rho])
+    h = 20.0
+    un, err, wr, its_o = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=1e-12, maxit=6000)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=1))
+    assert rel_l2(k.get_state(), un) < 1e-9
+    assert st.linear_its <= 4 * 20, st.linear_its
+    assert st.linear_its < its_o / 3
+    k.close()
