@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """`python -m ksfd_amd.solver @options ...` -- counterpart of the reference's ksfdsolver2.main
 (ksfdsolver2.py:642-774) with the PETSc TS replaced by the HIP stepper.  Same command-line syntax."""
+import os
 import sys
 
 import numpy as np
@@ -40,6 +41,41 @@ def start_values(ps, cfg, rng):
     return np.concatenate([f.ravel(order='F') for f in fields])          # SoA, x fastest
 
 
+class _Rank:
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+
+
+def open_ranks(cfg):
+    """One process per GPU under torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE), the counterpart of the reference's
+    `mpiexec -n P` SPMD launch (ksfdsolver2.py:650-652).  Returns (KSFDHip, _Rank, keepalive).
+    Environment: KSFD_TRANSPORT=auto|rccl|host, KSFD_DIST_BACKEND=nccl|gloo, KSFD_SHARE_GPU=1 (all ranks on device 0:
+    rehearsal on a one-GPU box)."""
+    from . import lib as klib
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return klib.KSFDHip(cfg), _Rank(0, 1), None
+    import torch
+    import torch.distributed as dist
+    from .dist import open_handle
+    rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    dev = 0 if os.environ.get('KSFD_SHARE_GPU') else local
+    backend = os.environ.get('KSFD_DIST_BACKEND', 'nccl')
+    host_group = None
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        else:
+            dist.init_process_group('gloo')
+    if dist.get_backend() == 'nccl':
+        host_group = dist.new_group(backend='gloo')
+    default_tr = 'auto' if dist.get_backend() == 'nccl' else 'host'
+    ks, keep = open_handle(cfg, rank, world, dev, transport=os.environ.get('KSFD_TRANSPORT', default_tr), host_group=host_group)
+    return ks, _Rank(rank, world), keep
+
+
 def main(*args):
     argv = list(args) if args else sys.argv
     cl = opt.parse_commandline(argv[1:])
@@ -52,23 +88,30 @@ def main(*args):
         return None
     cfg = ps.problem_config()
     sources = opt.decode_sources(cl.source, ps)
+    ks, rk, keep = open_ranks(cfg)
+    # initial data: the global field from the rank-0 stream on every rank (identical for any number of ranks), then
+    # this rank's slab; noise injection later draws from the per-rank stream like the reference (ksfdrandom.py:44-49)
     rng = reference_rng(cl.seed)
-    derivs = Derivatives(ps, cfg, sources)
+    derivs = Derivatives(ps, cfg, sources, ks=ks, dist=rk if rk.size > 1 else None)
     from .layout import SOA, HDF5
+    from .dist import local_slab
     v = ps.values0
     t_start, dt0, k0 = ps.t0, float(v['dt']), 0
     resuming = cl.resume or cl.restart
     if resuming:
         # ksfdsolver2.py:525-578: last point of the series; --resume keeps its time and dt, --restart starts at t0
         from .timeseries import read_last
-        k_last, t_last, data, info, _ = read_last(resuming)
+        k_last, t_last, data, info, _ = read_last(resuming, size=rk.size, rank=rk.rank)
         derivs.ks.set_state(np.ascontiguousarray(data).ravel(), HDF5)
         if cl.resume:
             t_start = t_last
             if 'dt' not in ps.given and 'dt' in info:
                 dt0 = float(info['dt'])
     else:
-        derivs.ks.set_state(start_values(ps, cfg, rng), SOA)
+        u0 = start_values(ps, cfg, rng)
+        derivs.ks.set_state(local_slab(u0, cfg, rk.rank, rk.size) if rk.size > 1 else u0, SOA)
+        if rk.size > 1:
+            rng = reference_rng(cl.seed, rank=rk.rank, size=rk.size)
     ts = implicitTS(derivs, t0=t_start, dt=dt0, tmax=float(v['tmax']),
                     maxsteps=0 if cl.onestep else int(v['maxsteps']), rtol=float(v['rtol']), atol=float(v['atol']),
                     opts=opt.step_opts_from(ps, cl.petsc), rng=rng)

@@ -106,3 +106,35 @@ def test_slab_ranks_match_single_rank_host_transport(size, shape, nlig, tmp_path
 
 def test_slab_ranks_match_single_rank_rccl(tmp_path):
     _run(2, (64, 48), 1, 'rccl', tmp_path)
+
+
+def _solver_worker(rank, size, port, optfile, prefix):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(size), KSFD_DIST_BACKEND='gloo', KSFD_SHARE_GPU='1')
+    from ksfd_amd import solver
+    ts = solver.main('ksfd', optfile, '--save=' + prefix)
+    assert ts.getStepNumber() == 25 and not ts.diverged
+    ts.cleanup()
+    dist.destroy_process_group()
+
+
+def test_solver_main_on_two_ranks_matches_one_rank(tmp_path):
+    """`torchrun -m ksfd_amd.solver @options` (here: 2 ranks sharing cuda:0 over gloo): per-rank series files
+    <prefix>s2r<rank>.* whose slabs, put side by side, equal the single-rank run."""
+    from conftest import GOLDEN
+    from ksfd_amd import solver
+    from ksfd_amd.timeseries import read_series
+    optfile = '@' + os.path.join(GOLDEN, 'options', 'ks2d_two_ligands.txt')
+    p2 = str(tmp_path / 'two' / 'run')
+    mp.spawn(_solver_worker, args=(2, _free_port(), optfile, p2), nprocs=2, join=True)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        os.environ.pop(k, None)
+    p1 = str(tmp_path / 'one' / 'run')
+    ts = solver.main('ksfd', optfile, '--save=' + p1)
+    ts.cleanup()
+    one = read_series(p1)
+    parts = [read_series(p2, size=2, rank=r) for r in range(2)]
+    assert np.allclose(parts[0]['times'], one['times'], rtol=1e-9, atol=0)
+    both = np.concatenate([parts[0]['data'][25], parts[1]['data'][25]], axis=2)      # (dof, nx, ny): slabs along y
+    assert both.shape == one['data'][25].shape
+    assert rel_l2(both, one['data'][25]) < 1e-8
