@@ -43,7 +43,7 @@ def main():
     ap.add_argument('--grid', dest='n', type=int, default=4096, help='points per axis')
     ap.add_argument('--nlig', type=int, default=1)
     ap.add_argument('--dim', type=int, default=2, help='2 (headline) or 3 (BASELINE configs[4]-style, generic kernels)')
-    ap.add_argument('--dt', type=float, default=0.05, help='first trial step (the controller adapts from here)')
+    ap.add_argument('--dt', type=float, default=0.01, help='first trial step (the controller adapts from here)')
     ap.add_argument('--fixed-h', type=float, default=0.0, help='>0: -ts_adapt_type none with this step')
     ap.add_argument('--ksp-rtol', type=float, default=1e-6,
                     help='GMRES relative residual; 1e-6 keeps the fields within ~1e-10 rel-L2 of a 1e-12 solve')

@@ -13,6 +13,7 @@ Two transports feed include/ksfd_hip.h:ksfd_dist:
      sharing one GPU).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -150,7 +151,7 @@ def open_handle(cfg, rank, size, device, transport='auto', group=None, host_grou
         if transport == 'rccl':
             raise RuntimeError('RCCL transport unavailable: ' + why)
         if rank == 0:
-            print('[ksfd_amd.dist] RCCL transport unavailable (%s); using host-callback transport' % why, flush=True)
+            print('[ksfd_amd.dist] RCCL transport unavailable (%s); using host-callback transport' % why, file=sys.stderr, flush=True)
     ring = HostRing(g)
     ks = klib.KSFDHip(cfg, ring.cdist(device))
     ks._ring = ring

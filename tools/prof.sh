@@ -2,7 +2,7 @@
 # Runs on the GPU box: rocprofv3 kernel trace + stats of the default bench, then two PMC passes (HBM bytes).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_r1
+OUT=$R/gpurun_out/${PROF_TAG:-prof_r1}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_under_rocprof.log 2>&1
