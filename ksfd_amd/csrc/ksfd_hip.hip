@@ -1553,6 +1553,26 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                            : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc);
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
+            if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
+                // unpreconditioned GMRES ran out of iterations: the multigrid-preconditioned solve of the same system
+                // is the remedy (the stiffness estimate above only knows the diffusion part of J)
+                rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, true);
+                st.linear_its += ls.its;
+                st.ksp_resid = ls.rel;
+            }
+        }
+        if (rc == KSFD_ELINEAR && opts->adapt && max_rej >= 0 && rejects < max_rej && hh * 0.25 >= opts->dt_min) {
+            // PETSc's -ts_adapt_scale_solve_failed (0.25): a failed solve rejects the step and quarters it.  The
+            // reference disables that by setMaxSNESFailures(1) (KSFD/ksfdts.py:135) because its LU cannot fail this
+            // way; an iterative solve can, and aborting a long run for it would not be a service.
+            rejects++;
+            st.rejections = rejects;
+            prev_accept = false;
+            if ((rc = op_copy(h, h->u, h->usave))) goto out;
+            hh *= 0.25;
+            *hstep = hh;
+            if ((rc = halo(h, h->u))) goto out;
+            continue;
         }
         if (rc) { op_copy(h, h->u, h->usave); hipStreamSynchronize(h->st); goto out; }
         // completion + embedded error norm

@@ -214,3 +214,31 @@ def test_multigrid_3d_stiff_step_vs_oracle_lu():
     assert st.linear_its <= 4 * 20, st.linear_its
     assert st.linear_its < its_o / 3
     k.close()
+
+
+def test_failed_linear_solve_falls_back():
+    """(a) unpreconditioned GMRES out of iterations -> the same system is re-solved with the multigrid preconditioner;
+    (b) without multigrid and with the controller on, the step is rejected and quartered instead of aborting the run"""
+    cfg = ProblemConfig.standard(2, (32, 32), L=(0.08, 0.08), nlig=1)
+    rng = np.random.default_rng(12)
+    rho = 9000 + 90 * rng.standard_normal(32 * 32)
+    u = np.concatenate([rho, rho])
+    k = klib.KSFDHip(cfg)
+    # (a) h small enough that the stiffness estimate does not switch multigrid on by itself, iteration cap too low
+    k.set_state(u)
+    o = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-9, ksp_max_it=12, pc_type=2)
+    t, hn, st, rc = k.step(0.0, 0.02, o, raise_on_error=False)
+    assert rc == 0 and st.accepted, k.last_error()
+    un, _, _, _ = ko.Oracle(cfg).rosw_step(u, 0.02, 0.01, 1e-6, solver='lu')
+    assert rel_l2(k.get_state(), un) < 1e-9
+    # (b) no preconditioner allowed, controller on: quartered until 6 iterations are enough
+    k.set_state(u)
+    o = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=1e-8, ksp_max_it=6, pc_type=0)
+    t, hn, st, rc = k.step(0.0, 0.02, o, raise_on_error=False)
+    assert rc == 0 and st.accepted and st.rejections >= 1 and st.h_used <= 0.02 / 4
+    # controller off: the failure is reported (reference semantics: SNES failure ends the run)
+    k.set_state(u)
+    o = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-8, ksp_max_it=6, pc_type=0)
+    t, hn, st, rc = k.step(0.0, 0.02, o, raise_on_error=False)
+    assert rc == klib.ELINEAR and not st.accepted and np.array_equal(k.get_state(), ko.Oracle(cfg).groom(u))
+    k.close()

@@ -11,6 +11,8 @@ nlig = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 cfg = ProblemConfig.standard(2, (n, n), L=(n / 384.0, n / 384.0), nlig=nlig)      # options81 spacing (width 1 at 384)
 ks = klib.KSFDHip(cfg)
 ks.set_state(start_values(cfg))
+if len(sys.argv) > 4:
+    ks.set_mg_params(nu=int(sys.argv[4]))
 opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
 t, h = 0.0, 1e-8
 T0 = time.perf_counter()
