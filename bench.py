@@ -86,6 +86,8 @@ def main():
     ks, keep = open_handle(cfg, rank, world, dev, transport=args.transport, group=None, host_group=host_group)
     if args.yseg:
         ks.set_tuning(yseg=args.yseg)
+    if os.environ.get('KSFD_POLY_DEG'):
+        ks.set_poly_params(int(os.environ['KSFD_POLY_DEG']), float(os.environ.get('KSFD_POLY_TARGET', '0')))
     if os.environ.get('KSFD_TUNE'):                      # A/B switches of ksfd_set_tuning (tools/async_bench.py)
         ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
     ks.set_state(local_slab(u0, cfg, rank, world) if world > 1 else u0)

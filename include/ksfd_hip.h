@@ -91,7 +91,8 @@ typedef struct ksfd_step_opts {
     double safety, reject_safety; /* 0.9, 0.5 */
     double ksp_rtol, ksp_atol;  /* GMRES: stop at ||r|| <= max(ksp_rtol*||b||, ksp_atol) */
     int32_t ksp_restart, ksp_max_it;
-    int32_t pc_type;            /* 0 none; 1 geometric multigrid V cycle (2-D, one rank); 2 = multigrid only when stiff (default) */
+    int32_t pc_type;            /* 0 none; 1 geometric multigrid V cycle always; 2 automatic (default): multigrid when the step is
+                                 * stiff, Chebyshev polynomial + flexible GMRES when mildly stiff, none when not; 3 polynomial only */
     int32_t reserved;           /* 0: CGS2 with algebraic second projection (default); 1: classic two-pass CGS2 */
 } ksfd_step_opts;
 
@@ -177,6 +178,9 @@ int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the
  * Chebyshev bound, smoothing interval ratio lambda_max/lambda_min, coarsest-grid reduction target */
 int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t power_its, double ratio, double coarse_tol);
+/* Chebyshev polynomial preconditioner: highest degree (default 3; 0 = off) and the residual reduction per outer
+ * iteration that picks the degree (default 0.02; <= 0 keeps) */
+int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target);
 
 #ifdef __cplusplus
 }

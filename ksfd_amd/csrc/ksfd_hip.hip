@@ -95,6 +95,16 @@ struct ksfd_handle {
     int async_mode = 0;             // 0 off (default: measured no gain on one GPU, tools/async_bench.py), 1 whenever legal,
                                     // 2 when the local problem is small
 
+    // polynomial (Chebyshev) preconditioner + flexible GMRES (see poly_setup / gmres)
+    double *Zb = nullptr;           // preconditioned basis z_j = p(A) v_j (allocated on first use)
+    double *pvec = nullptr;         // power-iteration vector for lambda_max(A)
+    double lamJ = -1.0;             // running estimate of lambda_max(-J) = lambda_max(A) - shift
+    int poly_deg = 0;
+    double poly_alpha[8];           // z = sum_i alpha_i (A/shift)^i v
+    double poly_shift = -1.0;
+    int poly_max_deg = 3;
+    double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
+
     // multigrid preconditioner
     std::vector<MGLevel> mg;
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
@@ -365,14 +375,15 @@ static int op_jcoef(ksfd_handle *h, const double *u)
 }
 
 // Jacobian action from the frozen coefficients (see stencil.hip.h, "Frozen-Jacobian path")
-static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift, double *out)
+static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift, double *out,
+                         const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
 {
     const KGeom &G = h->G;
     const double nplanes = (3 + h->P.nlig) + 2.0 * G.F;
     if (fused_ok(h)) {
         KStrips K = make_strips(h, true);
         Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta));
     } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -392,7 +403,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
         K.nblocks = (int)((nb3 + 7) / 8 * 8);
         Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -402,7 +413,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
         // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out));
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -412,15 +423,16 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
 //   compute stream: [interior segments]                      [two boundary segments]
 //   comm stream   :   wait(v ready) -> ghost rows of v <- ring neighbours -> signal
 // Interior segments read owned rows only; the first and last segment are the only readers of ghost rows.
-static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift, double *out)
+static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift, double *out,
+                              const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
 {
     int rc;
     const KGeom &G = h->G;
-    if (h->size == 1) return op_jvp_frozen(h, v, mode, shift, out);
+    if (h->size == 1) return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
     KStrips K = make_strips(h, true);
     if (!h->overlap || !fused_ok(h) || K.nseg < 3 || h->P.nlig > 4) {
         if ((rc = halo(h, v))) return rc;
-        return op_jvp_frozen(h, v, mode, shift, out);
+        return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
     }
     const double nplanes = (3 + h->P.nlig) + 2.0 * G.F;
     const int nseg_total = K.nseg;
@@ -431,7 +443,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
         long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
         Ki.nblocks = (int)((nb + 7) / 8 * 8);
         Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * (double)Ki.nseg / nseg_total);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Ki.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Ki, (const double *)h->coef, (const double *)v, mode, shift, out));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Ki.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Ki, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
     }
     HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
     {
@@ -446,7 +458,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
         long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
         Kb.nblocks = (int)((nb + 7) / 8 * 8);
         Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * 2.0 / nseg_total);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Kb.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Kb, (const double *)h->coef, (const double *)v, mode, shift, out));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Kb.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Kb, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -577,7 +589,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->st) hipStreamSynchronize(h->st);
-    double *bufs[] = { h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
+    double *bufs[] = { h->Zb, h->pvec, h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
     for (double *b : bufs) if (b) hipFree(b);
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
     if (h->hres) hipHostFree(h->hres);
@@ -1217,6 +1229,89 @@ static int mg_precond(ksfd_handle *h, double shift, const double *in, double *ou
 }
 
 // ------------------------------------------------------------------------------------------------
+// Polynomial preconditioner.  In the non-stiff regime (h*gamma*lambda_max(J) of order 1..10, the regime of the
+// headline benchmark) plain GMRES needs ~7 iterations per stage and spends most of its time in Gram-Schmidt, whose
+// traffic grows with the square of the iteration count.  z = p(A) v with p the degree-d Chebyshev approximation of
+// 1/lambda on [a, b] (spectrum of A/shift: a ~ 1, b = 1 + lambda_max(-J)/shift) costs d Jacobian actions with a fused
+// Horner epilogue (out = alpha*v + beta*A t, no extra pass) and cuts the outer iterations to 2-3: same number of
+// Jacobian actions, a fraction of the Gram-Schmidt passes.  Used through flexible GMRES (Z basis kept), so the
+// solution update needs no extra preconditioner application.
+// ------------------------------------------------------------------------------------------------
+static int est_lambda_max(ksfd_handle *h, double shift, int nits)
+{
+    int rc;
+    if (!h->pvec) {
+        if (alloc_d(h, &h->pvec, h->vlen)) return KSFD_ENOMEM;
+        int nb = (int)std::min<long long>((h->vlen + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)h->vlen, h->pvec);
+        if ((rc = op_multidot(h, h->pvec, h->pvec, 0))) return rc;
+        const double n0 = sqrt(h->hres[0]);
+        const double *xs[1] = { h->pvec }; double a[1] = { 1.0 / n0 };
+        if ((rc = op_lincomb(h, 1, xs, a, h->pvec))) return rc;
+    }
+    double lamA = 0.0;
+    for (int it = 0; it < nits; it++) {
+        if ((rc = op_jvp_frozen_halo(h, h->pvec, 1, shift, h->t3))) return rc;
+        if ((rc = op_multidot(h, h->t3, h->t3, 0))) return rc;
+        lamA = sqrt(h->hres[0]);
+        if (!(lamA > 0.0) || lamA != lamA) return fail(h, KSFD_ENAN, "power iteration on the Jacobian broke down");
+        const double *xs[1] = { h->t3 }; double a[1] = { 1.0 / lamA };
+        if ((rc = op_lincomb(h, 1, xs, a, h->pvec))) return rc;
+    }
+    const double est = lamA - shift;
+    h->lamJ = est > 0.0 ? est : 0.0;
+    return KSFD_OK;
+}
+
+// coefficients of p for this shift; degree 0 = "do not precondition"
+static void poly_setup(ksfd_handle *h, double shift)
+{
+    const double a = 0.97, b = 1.0 + 1.15 * h->lamJ / shift;      // spectrum of A/shift (power iteration converges from below: +15 %)
+    h->poly_shift = shift;
+    h->poly_deg = 0;
+    const double kappa = b / a;
+    if (kappa < 1.3) return;                                       // GMRES alone needs <= 3 iterations
+    const double rc_ = (sqrt(kappa) - 1.0) / (sqrt(kappa) + 1.0);
+    int d = (int)ceil(log(h->poly_target) / log(rc_)) - 1;         // residual polynomial of degree d+1: ~2 rc^(d+1) <= 2*target
+    d = std::min(std::max(d, 1), std::max(h->poly_max_deg, 1));
+    // r(l) = T_{d+1}(mu(l)) / T_{d+1}(mu(0)), mu(l) = m0 + m1 l;  p(l) = (1 - r(l)) / l
+    const int n = d + 1;
+    double m0 = (b + a) / (b - a), m1 = -2.0 / (b - a);
+    double Tp[10] = { 1.0 }, Tc[10] = { m0, m1 }, Tn[10];
+    int degc = 1;
+    for (int k = 1; k < n; k++) {
+        for (int i = 0; i < 10; i++) Tn[i] = 0.0;
+        for (int i = 0; i <= degc; i++) { Tn[i] += 2.0 * m0 * Tc[i]; Tn[i + 1] += 2.0 * m1 * Tc[i]; }
+        for (int i = 0; i <= degc - 1; i++) Tn[i] -= Tp[i];
+        for (int i = 0; i < 10; i++) { Tp[i] = Tc[i]; Tc[i] = Tn[i]; }
+        degc++;
+    }
+    const double t0 = Tc[0];                                       // T_n(mu(0))
+    for (int i = 0; i <= d; i++) h->poly_alpha[i] = -(Tc[i + 1] / t0) / shift;   // p_i = -r_{i+1}; the 1/shift turns p(A/shift) into ~A^-1
+    h->poly_deg = d;
+}
+
+// z = sum_i alpha_i (A/shift)^i v  by Horner, one fused Jacobian action per degree
+static int poly_apply(ksfd_handle *h, double shift, double *v, double *z)
+{
+    int rc;
+    const int d = h->poly_deg;
+    const double *al = h->poly_alpha;
+    double *tmp[2] = { h->t1, h->t2 };
+    // t_{d-1} = alpha_{d-1} v + (alpha_d/shift) A v
+    double *cur = (d == 1) ? z : tmp[0];
+    if ((rc = op_jvp_frozen_halo(h, v, 3, shift, cur, v, al[d - 1], al[d] / shift))) return rc;
+    int flip = 1;
+    for (int i = d - 2; i >= 0; i--) {
+        double *nxt = (i == 0) ? z : tmp[flip];
+        if ((rc = op_jvp_frozen_halo(h, cur, 3, shift, nxt, v, al[i], 1.0 / shift))) return rc;
+        cur = nxt;
+        flip ^= 1;
+    }
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // matrix-free GMRES(m) for (shift I - J(u)) x = b, x0 = 0  -- replaces -ksp_type preonly -pc_type lu
 // (options84:58-60).  Classical Gram-Schmidt applied twice (CGS2), one fused multi-dot + one fused
 // update kernel per pass; the new vector's norm comes from the second pass by Pythagoras.
@@ -1224,8 +1319,10 @@ static int mg_precond(ksfd_handle *h, double shift, const double *in, double *ou
 struct LinStats { int its; double rel; };
 
 static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
-                 const ksfd_step_opts *o, LinStats *ls, bool use_pc)
+                 const ksfd_step_opts *o, LinStats *ls, int pcmode)
 {
+    const bool use_pc = pcmode == 1;       // multigrid, right preconditioning
+    const bool use_poly = pcmode == 2;     // Chebyshev polynomial, flexible GMRES (z_j kept in Zb)
     // use_pc: right preconditioning with one multigrid V cycle, w = A (M^-1 v_j), x = M^-1 (V y)
     auto apply_A = [&](const double *vin, double *wout) -> int {
         return h->use_frozen ? op_jvp_frozen(h, vin, 1, shift, wout) : op_jvp(h, ustate, vin, 1, shift, wout);
@@ -1271,6 +1368,9 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
             if (use_pc) {
                 if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
+            } else if (use_poly) {
+                double *zj = h->Zb + (int64_t)j * vs;
+                if ((rc = poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
             } else if (h->use_frozen) {
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
@@ -1351,7 +1451,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
             if (first) { if ((rc = op_copy(h, x, h->t1))) return rc; }
             else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
-        } else if ((rc = op_basis_axpy(h, x, V, j, y.data(), first ? 0.0 : 1.0))) return rc;
+        } else if ((rc = op_basis_axpy(h, x, use_poly ? h->Zb : V, j, y.data(), first ? 0.0 : 1.0))) return rc;
         first = false;
         if (done || total >= maxit) break;
     }
@@ -1507,6 +1607,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     const int64_t vs = h->vlen;
     double hh = *hstep;
     bool prev_accept = true;
+    bool lam_done = false;
     int rejects = 0;
     const int max_rej = opts->max_reject;
     // KSFDTS.solve grooms the global vector before every TS.step (KSFD/ksfdts.py:210)
@@ -1515,6 +1616,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     if ((rc = halo(h, h->u))) goto out;
     if (h->use_frozen && (rc = op_jcoef(h, h->u))) goto out;
     h->mg_coef_valid = false; h->mg_shift = -1.0;
+    h->poly_shift = -1.0;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
         // stiffness estimate h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~8
@@ -1525,8 +1627,19 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const bool use_pc = h->mg_ok && h->use_frozen && opts->pc_type && (opts->pc_type == 1 || stiff > 8.0);
         // pipelined solver: latency-bound iterations only (small local problem), not in the tiny-h regime where the
         // Pythagorean norm update cancels heavily (|w|^2/h_n^2 ~ 1/stiff^2) and gmres() takes its explicit second pass
+        // polynomial preconditioner in the mildly stiff regime (pc_type 2 = automatic, 3 = polynomial whenever useful)
+        bool use_poly = false;
+        if (!use_pc && h->use_frozen && (opts->pc_type == 2 || opts->pc_type == 3) && stiff >= 0.3) {
+            if (!h->Zb && alloc_d(h, &h->Zb, (int64_t)h->restart_alloc * h->vlen)) { rc = KSFD_ENOMEM; goto out; }
+            if (!lam_done) {
+                if ((rc = est_lambda_max(h, shift, h->lamJ < 0.0 ? 8 : 2))) goto out;      // warm-started after the first step
+                lam_done = true;
+            }
+            if (h->poly_shift != shift) poly_setup(h, shift);
+            use_poly = h->poly_deg >= 1 && h->poly_max_deg >= 1;
+        }
         const bool small = (double)h->G.F * (double)h->G.nloc <= 6.0e6;
-        const bool use_async = !use_pc && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
+        const bool use_async = !use_pc && !use_poly && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
                                (h->size == 1 || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
         for (int i = 0; i < 4 && !rc; i++) {
@@ -1550,13 +1663,13 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             LinStats ls;
             rc = use_async ? gmres_async(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls)
-                           : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc);
+                           : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0));
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
             if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
                 // unpreconditioned GMRES ran out of iterations: the multigrid-preconditioned solve of the same system
                 // is the remedy (the stiffness estimate above only knows the diffusion part of J)
-                rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, true);
+                rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, 1);
                 st.linear_its += ls.its;
                 st.ksp_resid = ls.rel;
             }
@@ -1664,6 +1777,14 @@ extern "C" int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_ma
     if (coarse_tol > 0.0) h->mg_coarse_tol = coarse_tol;
     h->mg_use_graph = power_its != -7;     // power_its = -7: eager launches (debug / A-B timing)
     h->mg_shift = -1.0;
+    return KSFD_OK;
+}
+extern "C" int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target)
+{
+    if (!h || max_degree < 0 || max_degree > 6) return KSFD_EINVAL;
+    h->poly_max_deg = max_degree;           // 0 disables the polynomial preconditioner
+    if (target > 0.0 && target < 1.0) h->poly_target = target;
+    h->poly_shift = -1.0;
     return KSFD_OK;
 }
 extern "C" int ksfd_synchronize(ksfd_handle *h)

@@ -138,8 +138,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
                                                             const double *__restrict__ v,
                                                             const double *__restrict__ Gb,
                                                             const double *__restrict__ dGb, int mode, double shift,
-                                                            double *__restrict__ out, const double *__restrict__ yadd = nullptr)
+                                                            double *__restrict__ out, const double *__restrict__ yadd = nullptr,
+                                                            double alpha = 0.0, double beta = 0.0)
 {
+    // mode 0: J v | 1: shift v - J v | 2: yadd - (shift v - J v) | 3: alpha*yadd + beta*(shift v - J v)
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
         long long i, j, k;
@@ -172,12 +174,14 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
         double jr = acc + v0 * lapG + rho0 * lapdG;
         double o0 = mode ? shift * v0 - jr : jr;
         if (mode == 2) o0 = yadd[o] - o0;
+        else if (mode == 3) o0 = alpha * yadd[o] + beta * o0;
         out[o] = o0;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             double ju = -P.lig_gamma[l] * V0[l] + P.lig_s[l] * v0 + P.lig_D[l] * lapV[l];
             double ol = mode ? shift * V0[l] - ju : ju;
             if (mode == 2) ol = yadd[(long long)(l + 1) * G.plane + o] - ol;
+            else if (mode == 3) ol = alpha * yadd[(long long)(l + 1) * G.plane + o] + beta * ol;
             out[(long long)(l + 1) * G.plane + o] = ol;
         }
     }
@@ -543,9 +547,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const double *__restrict__ C,
                                                              const double *__restrict__ v, int mode, double shift,
-                                                             double *__restrict__ out, const double *__restrict__ yadd = nullptr)
+                                                             double *__restrict__ out, const double *__restrict__ yadd = nullptr,
+                                                             double alpha = 0.0, double beta = 0.0)
 {
-    // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x)
+    // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x) ;
+    // 3: out = alpha*yadd + beta*(shift*v - J v)   (one Horner step of the polynomial preconditioner; yadd may be v)
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;
     double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
@@ -630,7 +636,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
-                if (mode == 2) { const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o); a = yy.x - a; b = yy.y - b; }
+                if (mode >= 2) {
+                    const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o);
+                    if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
+                }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
             }
         }
@@ -663,7 +672,7 @@ template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K3D S, const double *__restrict__ C,
                                                              const double *__restrict__ v, const double *__restrict__ dG,
                                                              int mode, double shift, double *__restrict__ out,
-                                                             const double *__restrict__ yadd = nullptr)
+                                                             const double *__restrict__ yadd = nullptr, double alpha = 0.0, double beta = 0.0)
 {
     const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x >> 6;
     const long long bid = ksfd_xcd_remap(blockIdx.x, S.nblocks);
@@ -784,7 +793,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
-                if (mode == 2) { const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o); a = yy.x - a; b = yy.y - b; }
+                if (mode >= 2) {
+                    const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o);
+                    if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
+                }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
             }
         }

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
     'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho',
     'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
-    'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params',
+    'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params', 'ksfd_set_poly_params',
 ]
 
 
@@ -120,6 +120,7 @@ def load():
     L.ksfd_bench_kernel.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.ksfd_set_mg_params.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]
+    L.ksfd_set_poly_params.argtypes = [vp, C.c_int32, C.c_double]
     _lib = L
     return L
 
@@ -289,6 +290,9 @@ class KSFDHip:
 
     def set_mg_params(self, nu=0, ncoarse_max=0, power_its=0, ratio=0.0, coarse_tol=0.0):
         self._chk(self.L.ksfd_set_mg_params(self.h, nu, ncoarse_max, power_its, ratio, coarse_tol))
+
+    def set_poly_params(self, max_degree, target=0.0):
+        self._chk(self.L.ksfd_set_poly_params(self.h, int(max_degree), float(target)))
 
     def set_tuning(self, use_fused=-1, yseg=0, yseg_jvp=None):
         """use_fused: bit0 = fused 2-D kernels, bit1 = recompute (non-frozen) Jacobian action."""
