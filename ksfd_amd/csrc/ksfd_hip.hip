@@ -99,6 +99,7 @@ struct ksfd_handle {
     double *Zb = nullptr;           // preconditioned basis z_j = p(A) v_j (allocated on first use)
     double *pvec = nullptr;         // power-iteration vector for lambda_max(A)
     double lamJ = -1.0;             // running estimate of lambda_max(-J) = lambda_max(A) - shift
+    int lam_age = 0, lam_period = 1;   // steps since the last estimate / re-estimate every lam_period steps (1..8, grows while stable)
     int poly_deg = 0;
     double poly_alpha[8];           // z = sum_i alpha_i (A/shift)^i v
     double poly_shift = -1.0;
@@ -1300,7 +1301,7 @@ static int poly_apply(ksfd_handle *h, double shift, double *v, double *z)
     double *tmp[2] = { h->t1, h->t2 };
     // t_{d-1} = alpha_{d-1} v + (alpha_d/shift) A v
     double *cur = (d == 1) ? z : tmp[0];
-    if ((rc = op_jvp_frozen_halo(h, v, 3, shift, cur, v, al[d - 1], al[d] / shift))) return rc;
+    if ((rc = op_jvp_frozen_halo(h, v, 4, shift, cur, nullptr, al[d - 1], al[d] / shift))) return rc;
     int flip = 1;
     for (int i = d - 2; i >= 0; i--) {
         double *nxt = (i == 0) ? z : tmp[flip];
@@ -1632,7 +1633,14 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         if (!use_pc && h->use_frozen && (opts->pc_type == 2 || opts->pc_type == 3) && stiff >= 0.3) {
             if (!h->Zb && alloc_d(h, &h->Zb, (int64_t)h->restart_alloc * h->vlen)) { rc = KSFD_ENOMEM; goto out; }
             if (!lam_done) {
-                if ((rc = est_lambda_max(h, shift, h->lamJ < 0.0 ? 8 : 2))) goto out;      // warm-started after the first step
+                if (h->lamJ < 0.0 || ++h->lam_age >= h->lam_period) {
+                    const double before = h->lamJ;
+                    if ((rc = est_lambda_max(h, shift, before < 0.0 ? 8 : 2))) goto out;    // warm-started after the first step
+                    // J changes slowly from step to step: while the estimate moves by < 2 %, look less often
+                    const bool stable = before > 0.0 && fabs(h->lamJ - before) <= 0.02 * before;
+                    h->lam_period = stable ? std::min(2 * h->lam_period, 8) : 1;
+                    h->lam_age = 0;
+                }
                 lam_done = true;
             }
             if (h->poly_shift != shift) poly_setup(h, shift);

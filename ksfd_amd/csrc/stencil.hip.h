@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
         double o0 = mode ? shift * v0 - jr : jr;
         if (mode == 2) o0 = yadd[o] - o0;
         else if (mode == 3) o0 = alpha * yadd[o] + beta * o0;
+        else if (mode == 4) o0 = alpha * v0 + beta * o0;
         out[o] = o0;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
             double ol = mode ? shift * V0[l] - ju : ju;
             if (mode == 2) ol = yadd[(long long)(l + 1) * G.plane + o] - ol;
             else if (mode == 3) ol = alpha * yadd[(long long)(l + 1) * G.plane + o] + beta * ol;
+            else if (mode == 4) ol = alpha * V0[l] + beta * ol;
             out[(long long)(l + 1) * G.plane + o] = ol;
         }
     }
@@ -551,7 +553,8 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                                                              double alpha = 0.0, double beta = 0.0)
 {
     // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x) ;
-    // 3: out = alpha*yadd + beta*(shift*v - J v)   (one Horner step of the polynomial preconditioner; yadd may be v)
+    // 3: out = alpha*yadd + beta*(shift*v - J v)   (one Horner step of the polynomial preconditioner) ;
+    // 4: out = alpha*v + beta*(shift*v - J v)      (first Horner step: no extra plane is read)
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;
     double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
@@ -636,7 +639,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
-                if (mode >= 2) {
+                if (mode == 4) {            // yadd is the input vector itself: its centre values are in the windows
+                    const double c0 = c == 0 ? vw[2][0] : zw[c > 0 ? c - 1 : 0][2][0], c1 = c == 0 ? vw[2][1] : zw[c > 0 ? c - 1 : 0][2][1];
+                    a = alpha * c0 + beta * a; b = alpha * c1 + beta * b;
+                } else if (mode >= 2) {
                     const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o);
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
@@ -793,7 +799,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
 #pragma unroll
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
-                if (mode >= 2) {
+                if (mode == 4) {            // yadd is the input vector itself: its centre values are in the windows
+                    const double c0 = c == 0 ? vw[2][0] : zw[c > 0 ? c - 1 : 0][2][0], c1 = c == 0 ? vw[2][1] : zw[c > 0 ? c - 1 : 0][2][1];
+                    a = alpha * c0 + beta * a; b = alpha * c1 + beta * b;
+                } else if (mode >= 2) {
                     const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o);
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
