@@ -164,7 +164,9 @@ void ksfd_default_step_opts(ksfd_step_opts *o);
 int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_step_opts *opts, ksfd_step_stats *stats);
 int ksfd_get_last_error_vector(ksfd_handle *h, double *err_host, int32_t layout); /* embedded-minus-main of last attempt */
 
-/* -- measurement */
+/* -- measurement
+ * on: 0 off; 1 HIP-event pair around every launch (costs ~8 us of device time per launch); 2+c events only around
+ * launches of kernel class c (launch and byte counters of the other classes keep running) */
 int ksfd_set_profiling(ksfd_handle *h, int32_t on);
 int ksfd_get_profile(ksfd_handle *h, ksfd_profile *p, int32_t reset);
 int ksfd_synchronize(ksfd_handle *h);
@@ -178,9 +180,10 @@ int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the
  * Chebyshev bound, smoothing interval ratio lambda_max/lambda_min, coarsest-grid reduction target */
 int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t power_its, double ratio, double coarse_tol);
-/* Chebyshev polynomial preconditioner: highest degree (default 3; 0 = off) and the residual reduction per outer
- * iteration that picks the degree (default 0.02; <= 0 keeps) */
-int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target);
+/* Chebyshev polynomial preconditioner: highest degree (default 6, at most 7; 0 = off), the residual reduction per
+ * outer iteration that picks the degree (default 0.02; <= 0 keeps), and the stiffness h*gamma*lambda_max(diffusion)
+ * above which pc_type 2 hands over to multigrid (default 60; <= 0 keeps) */
+int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target, double mg_threshold);
 
 #ifdef __cplusplus
 }

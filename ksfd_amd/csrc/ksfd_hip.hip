@@ -83,6 +83,7 @@ struct ksfd_handle {
 
     // profile
     bool profiling = false;
+    int prof_only = -1;             // >= 0: HIP events only around launches of this kernel class
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> pool;
     ksfd_profile prof;
@@ -103,7 +104,8 @@ struct ksfd_handle {
     int poly_deg = 0;
     double poly_alpha[8];           // z = sum_i alpha_i (A/shift)^i v
     double poly_shift = -1.0;
-    int poly_max_deg = 3;
+    int poly_max_deg = 6;
+    double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
 
     // multigrid preconditioner
@@ -150,7 +152,7 @@ static hipEvent_t ev_get(ksfd_handle *h)
 }
 struct Scope {
     ksfd_handle *h; EvPair p; bool on;
-    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling && !h_->capturing)
+    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling && !h_->capturing && (h_->prof_only < 0 || h_->prof_only == cls))
     {
         h->bytes_acc += bytes;
         h->prof.bytes[cls] += bytes;
@@ -1620,12 +1622,14 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     h->poly_shift = -1.0;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
-        // stiffness estimate h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~8
+        // stiffness estimate X = h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~60
         double dmax = h->P.s2, lap = 0.0;
         for (int l = 0; l < h->P.nlig; l++) dmax = std::max(dmax, h->P.lig_D[l]);
         for (int a = 0; a < h->G.dim; a++) lap += (16.0 / 3.0) * h->P.inv_h2[a];
         const double stiff = dmax * lap / shift;
-        const bool use_pc = h->mg_ok && h->use_frozen && opts->pc_type && (opts->pc_type == 1 || stiff > 8.0);
+        // (measured crossover against the degree-6 polynomial: X ~ 80 on 4096^2, ~ 280 on 1024^2 where the V cycle is latency-bound)
+        const double mg_from = h->mg_threshold * ((double)h->G.F * (double)h->G.nloc < 8.0e6 ? 3.0 : 1.0);
+        const bool use_pc = h->mg_ok && h->use_frozen && (opts->pc_type == 1 || (opts->pc_type == 2 && stiff > mg_from));
         // pipelined solver: latency-bound iterations only (small local problem), not in the tiny-h regime where the
         // Pythagorean norm update cancels heavily (|w|^2/h_n^2 ~ 1/stiff^2) and gmres() takes its explicit second pass
         // polynomial preconditioner in the mildly stiff regime (pc_type 2 = automatic, 3 = polynomial whenever useful)
@@ -1764,7 +1768,9 @@ extern "C" int ksfd_set_profiling(ksfd_handle *h, int32_t on)
 {
     if (!h) return KSFD_EINVAL;
     prof_resolve(h);
+    if (on < 0 || on >= 2 + KSFD_NKCLASS) return KSFD_EINVAL;
     h->profiling = on != 0;
+    h->prof_only = on >= 2 ? on - 2 : -1;
     return KSFD_OK;
 }
 extern "C" int ksfd_get_profile(ksfd_handle *h, ksfd_profile *p, int32_t reset)
@@ -1787,9 +1793,10 @@ extern "C" int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_ma
     h->mg_shift = -1.0;
     return KSFD_OK;
 }
-extern "C" int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target)
+extern "C" int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target, double mg_threshold)
 {
-    if (!h || max_degree < 0 || max_degree > 6) return KSFD_EINVAL;
+    if (!h || max_degree < 0 || max_degree > 7) return KSFD_EINVAL;
+    if (mg_threshold > 0.0) h->mg_threshold = mg_threshold;
     h->poly_max_deg = max_degree;           // 0 disables the polynomial preconditioner
     if (target > 0.0 && target < 1.0) h->poly_target = target;
     h->poly_shift = -1.0;

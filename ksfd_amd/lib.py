@@ -120,7 +120,7 @@ def load():
     L.ksfd_bench_kernel.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]
     L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.ksfd_set_mg_params.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]
-    L.ksfd_set_poly_params.argtypes = [vp, C.c_int32, C.c_double]
+    L.ksfd_set_poly_params.argtypes = [vp, C.c_int32, C.c_double, C.c_double]
     _lib = L
     return L
 
@@ -271,8 +271,13 @@ class KSFDHip:
         return out
 
     # ---- measurement
-    def set_profiling(self, on=True):
-        self._chk(self.L.ksfd_set_profiling(self.h, int(on)))
+    def set_profiling(self, on=True, only=None):
+        """only: kernel class name ('jvp', ...) -- time just that class (cheaper: each event pair costs device time)"""
+        code = int(bool(on))
+        if on and only is not None:
+            names = [self.L.ksfd_kernel_class_name(i).decode() for i in range(NKCLASS)]
+            code = 2 + names.index(only)
+        self._chk(self.L.ksfd_set_profiling(self.h, code))
 
     def profile(self, reset=False):
         p = Profile()
@@ -291,8 +296,8 @@ class KSFDHip:
     def set_mg_params(self, nu=0, ncoarse_max=0, power_its=0, ratio=0.0, coarse_tol=0.0):
         self._chk(self.L.ksfd_set_mg_params(self.h, nu, ncoarse_max, power_its, ratio, coarse_tol))
 
-    def set_poly_params(self, max_degree, target=0.0):
-        self._chk(self.L.ksfd_set_poly_params(self.h, int(max_degree), float(target)))
+    def set_poly_params(self, max_degree, target=0.0, mg_threshold=0.0):
+        self._chk(self.L.ksfd_set_poly_params(self.h, int(max_degree), float(target), float(mg_threshold)))
 
     def set_tuning(self, use_fused=-1, yseg=0, yseg_jvp=None):
         """use_fused: bit0 = fused 2-D kernels, bit1 = recompute (non-frozen) Jacobian action."""
