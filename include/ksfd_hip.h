@@ -156,6 +156,14 @@ int ksfd_count_worms(ksfd_handle *h, double *total);             /* sum(rho) ove
 int ksfd_scale_rho(ksfd_handle *h, double factor);               /* conserve_worms :248-256 */
 int ksfd_mul_rho(ksfd_handle *h, const double *factor_host);     /* add_variance: rho *= exp(sd*N(0,1)) :268-284; local SoA plane */
 
+/* -- assembled Jacobian export ("next" row f4): the matrix Derivatives.Jacobian + ksfdMat.setValuesJacobian assemble
+ *    (KSFD/ksfdsym.py:814-886, cython/ksfdMat/ksfdMat.pyx:55-180), evaluated at the resident (clamped) state, as CSR over
+ *    this rank's rows.  Ordering = the reference's PETSc Vec: unknown F*point + dof, point x-fastest; rows are numbered
+ *    from this rank's first owned point (rowptr starts at 0), columns are GLOBAL unknown indices (periodic wrap applied),
+ *    not sorted within a row.  Row of rho: F*(4*dim+1) entries; row of U_l: 4*dim+2.  Caller allocates from _nnz. */
+int ksfd_jacobian_nnz(ksfd_handle *h, int64_t *nrows_local, int64_t *nnz_local);
+int ksfd_jacobian_csr(ksfd_handle *h, int64_t *rowptr /* nrows+1 */, int64_t *col /* nnz */, double *val /* nnz */);
+
 /* -- the implicit step that replaces petsc4py TS.step() (KSFD/ksfdts.py:211):
  *    4-stage Rosenbrock-W RA34PW2 with frozen Jacobian J(t_n,u_n), shift 1/(gamma h), each stage
  *    solved matrix-free by restarted GMRES on the device; TSAdaptBasic error control.

@@ -382,7 +382,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
                          const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
 {
     const KGeom &G = h->G;
-    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F;
+    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
     if (fused_ok(h)) {
         KStrips K = make_strips(h, true);
         Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
@@ -405,7 +405,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
         long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
         K.nblocks = (int)((nb3 + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
@@ -414,7 +414,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
         }
         int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3) * (double)G.nloc);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
         // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     }
@@ -437,7 +437,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
         if ((rc = halo(h, v))) return rc;
         return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
     }
-    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F;
+    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
     const int nseg_total = K.nseg;
     HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
     {
@@ -888,6 +888,57 @@ extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
     hipLaunchKernelGGL(k_mul_rho, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, (const double *)h->flat, 1.0);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+// Assembled Jacobian export (row f4 of the scope table; kernel k_jac_csr in stencil.hip.h)
+extern "C" int ksfd_jacobian_nnz(ksfd_handle *h, int64_t *nrows, int64_t *nnz)
+{
+    if (!h) return KSFD_EINVAL;
+    const int64_t npts = 4 * h->G.dim + 1;
+    if (nrows) *nrows = (int64_t)h->G.F * h->G.nloc;
+    if (nnz) *nnz = h->G.nloc * ((int64_t)h->G.F * npts + (int64_t)h->P.nlig * (npts + 1));
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_jacobian_csr(ksfd_handle *h, int64_t *rowptr, int64_t *col, double *val)
+{
+    if (!h || !rowptr || !col || !val) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    int64_t nrows, nnz;
+    ksfd_jacobian_nnz(h, &nrows, &nnz);
+    int rc;
+    if ((rc = halo(h, h->u))) return rc;
+    if ((rc = op_jcoef(h, h->u))) return rc;                 // clamps like groom; the frozen planes are rebuilt by the next step anyway
+    h->mg_coef_valid = false; h->mg_shift = -1.0;
+    long long *dcol = nullptr;
+    double *dval = nullptr;
+    if (hipMalloc((void **)&dcol, sizeof(long long) * (size_t)nnz) != hipSuccess ||
+        hipMalloc((void **)&dval, sizeof(double) * (size_t)nnz) != hipSuccess) {
+        if (dcol) hipFree(dcol);
+        return fail(h, KSFD_ENOMEM, "hipMalloc of the CSR staging buffers failed");
+    }
+    const KGeom &G = h->G;
+    int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 65535);
+    {
+        Scope sc(h, KC_MISC, 16.0 * (double)nnz + 8.0 * (3 + h->P.nlig) * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jac_csr<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef,
+                                                  (long long)h->cfg.n[G.dim - 1], (long long)h->slow0, dcol, dval));
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(col, dcol, sizeof(long long) * (size_t)nnz, hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(val, dval, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    hipFree(dcol);
+    hipFree(dval);
+    if (e != hipSuccess) return fail(h, KSFD_EHIP, "jacobian export: %s", hipGetErrorString(e));
+    // row pointers are a fixed pattern: rho row F*npts entries, each U row npts+1
+    const int64_t npts = 4 * G.dim + 1, F = G.F, per = F * npts + (F - 1) * (npts + 1);
+    for (int64_t p = 0; p < G.nloc; p++) {
+        rowptr[p * F] = p * per;
+        for (int64_t l = 1; l < F; l++) rowptr[p * F + l] = p * per + F * npts + (l - 1) * (npts + 1);
+    }
+    rowptr[nrows] = nnz;
     return KSFD_OK;
 }
 

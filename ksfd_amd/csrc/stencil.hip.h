@@ -189,6 +189,74 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
     }
 }
 
+// Assembled Jacobian export: what Derivatives.Jacobian + ksfdMat.setValuesJacobian put
+// into the PETSc AIJ matrix (KSFD/ksfdsym.py:814-886, cython/ksfdMat/ksfdMat.pyx:55-180), as CSR values + GLOBAL column
+// indices in the reference's Vec ordering (unknown = F*point + dof, point x-fastest).  One thread per owned point,
+// coefficients from the frozen planes C = [rho, G, G_rho, G_U1..] (k_jcoef, ghosts filled).  Entry order per point:
+// rho row: for each dof, centre then axis by axis m = -2,-1,+1,+2;  U_l row: rho centre, U_l centre, the axes.
+// Not a hot path: the entry stores are strided.
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jac_csr(KGeom G, KPhys P, const double *__restrict__ C,
+                                                        long long gslow, long long slow0,
+                                                        long long *__restrict__ col, double *__restrict__ val)
+{
+    constexpr int F = NL + 1;
+    const int npts = 4 * G.dim + 1;
+    const long long per = (long long)F * npts + (long long)NL * (npts + 1);
+    const int slow = G.dim - 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
+        long long i, j, k;
+        ksfd_decode(G, p, i, j, k);
+        long long gi[3] = { i, j, k };
+        gi[slow] += slow0;
+        const long long gext[3] = { slow == 0 ? gslow : G.nx, slow == 1 ? gslow : G.ny, slow == 2 ? gslow : G.nz };
+        const long long gstr[3] = { 1, gext[0], gext[0] * gext[1] };
+        const long long gp = gi[0] + gi[1] * gstr[1] + gi[2] * gstr[2];
+        double d1g[3], d1r[3], lapG = 0.0, w2c = 0.0;
+        long long nl_[3][4], ng_[3][4], c0 = 0;
+        for (int a = 0; a < G.dim; a++) {
+            KNbr n = ksfd_nbr(G, a, i, j, k);
+            c0 = n.c;
+            const double *Gb = C + G.plane;
+            d1g[a] = KSFD_D1(Gb[n.m2], Gb[n.m1], Gb[n.p1], Gb[n.p2]) * P.inv_h[a];
+            d1r[a] = KSFD_D1(C[n.m2], C[n.m1], C[n.p1], C[n.p2]) * P.inv_h[a];
+            lapG += KSFD_D2(Gb[n.m2], Gb[n.m1], Gb[n.c], Gb[n.p1], Gb[n.p2]) * P.inv_h2[a];
+            w2c += -2.5 * P.inv_h2[a];
+            nl_[a][0] = n.m2; nl_[a][1] = n.m1; nl_[a][2] = n.p1; nl_[a][3] = n.p2;
+            const int ms[4] = { -2, -1, 1, 2 };
+            for (int m = 0; m < 4; m++)
+                ng_[a][m] = gp + (ksfd_wrap(gi[a] + ms[m], gext[a]) - gi[a]) * gstr[a];
+        }
+        const double rho0 = C[c0];
+        const double w1[4] = { 1.0 / 12.0, -2.0 / 3.0, 2.0 / 3.0, -1.0 / 12.0 };
+        const double w2[4] = { -1.0 / 12.0, 4.0 / 3.0, 4.0 / 3.0, -1.0 / 12.0 };
+        long long e = p * per;
+        for (int dof = 0; dof < F; dof++) {
+            const double *Gx = C + (long long)(2 + dof) * G.plane;       // G_rho, G_U1, ...
+            col[e] = gp * F + dof;
+            val[e++] = (dof == 0 ? lapG : 0.0) + rho0 * w2c * Gx[c0];
+            for (int a = 0; a < G.dim; a++)
+                for (int m = 0; m < 4; m++) {
+                    const double a1 = w1[m] * P.inv_h[a], a2 = w2[m] * P.inv_h2[a];
+                    col[e] = ng_[a][m] * F + dof;
+                    val[e++] = (dof == 0 ? a1 * d1g[a] : 0.0) + (a1 * d1r[a] + rho0 * a2) * Gx[nl_[a][m]];
+                }
+        }
+        for (int l = 0; l < NL; l++) {
+            col[e] = gp * F;
+            val[e++] = P.lig_s[l];
+            col[e] = gp * F + l + 1;
+            val[e++] = -P.lig_gamma[l] + P.lig_D[l] * w2c;
+            for (int a = 0; a < G.dim; a++)
+                for (int m = 0; m < 4; m++) {
+                    col[e] = ng_[a][m] * F + l + 1;
+                    val[e++] = P.lig_D[l] * w2[m] * P.inv_h2[a];
+                }
+        }
+    }
+}
+
 // Derivatives.velocity (KSFD/ksfdsym.py:1158-1209): v_a = D1a(G).  Writes dense dim*nloc planes when
 // vel != NULL and per-block per-axis max|v_a| partials (CFL_step, KSFD/ksfdts.py:302-319) when part != NULL.
 __global__ void __launch_bounds__(KSFD_BLOCK) k_velocity(KGeom G, KPhys P, const double *__restrict__ Gb,

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     'ksfd_kernel_class_name', 'ksfd_rccl_unique_id', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
     'ksfd_local_range', 'ksfd_local_size', 'ksfd_set_state', 'ksfd_get_state', 'ksfd_device_state',
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
-    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho',
+    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr',
     'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
     'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params', 'ksfd_set_poly_params',
 ]
@@ -110,6 +110,8 @@ def load():
     L.ksfd_count_worms.argtypes = [vp, dp]
     L.ksfd_scale_rho.argtypes = [vp, C.c_double]
     L.ksfd_mul_rho.argtypes = [vp, dp]
+    L.ksfd_jacobian_nnz.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.ksfd_jacobian_csr.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp]
     L.ksfd_default_step_opts.argtypes = [C.POINTER(StepOpts)]
     L.ksfd_default_step_opts.restype = None
     L.ksfd_step.argtypes = [vp, dp, dp, C.POINTER(StepOpts), C.POINTER(StepStats)]
@@ -251,6 +253,18 @@ class KSFDHip:
     def mul_rho(self, factor):
         f = self._vec(factor, self.nlocal // self.F)
         self._chk(self.L.ksfd_mul_rho(self.h, _dp(f)))
+
+    def jacobian_csr(self):
+        """Assembled df/du at the resident state: (rowptr, col, val), local rows, global columns, unknown = F*point + dof
+        (the reference's Vec ordering; KSFD/ksfdsym.py:814-886 + ksfdMat.pyx:55-180)."""
+        nr, nnz = C.c_int64(), C.c_int64()
+        self._chk(self.L.ksfd_jacobian_nnz(self.h, C.byref(nr), C.byref(nnz)))
+        rowptr = np.empty(nr.value + 1, dtype=np.int64)
+        col = np.empty(nnz.value, dtype=np.int64)
+        val = np.empty(nnz.value)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        self._chk(self.L.ksfd_jacobian_csr(self.h, ip(rowptr), ip(col), _dp(val)))
+        return rowptr, col, val
 
     # ---- step
     def step(self, t, h, opts=None, raise_on_error=True):

@@ -122,6 +122,19 @@ class Oracle:
         assert lib().ko_jvp(C.byref(self.k), _dp(u), _dp(v), _dp(out)) == 0
         return out
 
+    def jacobian_csr(self, u):
+        """(rowptr, col, val) of df/du at groom(u); unknowns ordered F*p + dof like the reference's Vec"""
+        u = self._in(u)
+        L = lib()
+        L.ko_jacobian_nnz.restype = C.c_int64
+        nnz = int(L.ko_jacobian_nnz(C.byref(self.k)))
+        rowptr = np.empty(self.F * self.N + 1, dtype=np.int64)
+        col = np.empty(nnz, dtype=np.int64)
+        val = np.empty(nnz)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        assert L.ko_jacobian_csr(C.byref(self.k), _dp(u), ip(rowptr), ip(col), _dp(val)) == 0
+        return rowptr, col, val
+
     def velocity(self, u):
         u = self._in(u)
         out = np.empty(int(self.cfg.dim) * self.N)

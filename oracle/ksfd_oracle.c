@@ -218,6 +218,95 @@ int ko_jvp(const ko_config *c, const double *u, const double *v, double *out)
     return 0;
 }
 
+/* Assembled analytic Jacobian df/du at the groomed state u, CSR, in the unknown ordering of the reference's PETSc
+ * Vec (row = F*p + dof, p = i + nx*(j + ny*k): DMDA dof-fastest, KSFD/ksfdgrid.py:388-411).  Restates
+ * Derivatives.Jacobian (KSFD/ksfdsym.py:814-886; rho-row entry fields :675-761, 1067-1127; U-row constants
+ * :630-673) followed by the scatter of ksfdMat.setValuesJacobian (cython/ksfdMat/ksfdMat.pyx:55-180).
+ *   d f_rho(p) / d rho(p)        = lap G + rho_p (sum_a w2_0/h_a^2) G_rho(p)
+ *   d f_rho(p) / d rho(p + m e_a) = w1_m/h_a D1_a(G) + (w1_m/h_a D1_a(rho) + rho_p w2_m/h_a^2) G_rho(p + m e_a)
+ *   d f_rho(p) / d U_l(q)         = same with G_Ul(q) and without the D1_a(G) term
+ *   d f_Ul(p)  / d rho(p) = s_l ;  d f_Ul(p) / d U_l(p + m e_a) = D_l w2_m/h_a^2 ;  centre: -gamma_l + D_l sum_a w2_0/h_a^2
+ * Entries per point: F*npts (rho row) + nlig*(npts+1) (U rows), npts = 4*dim+1.  Order inside a rho row: for each
+ * dof, centre then axis by axis m = -2,-1,+1,+2; inside a U_l row: rho centre, U_l centre, then the axes.
+ * Columns are not sorted.  rowptr has F*N+1 entries. */
+int64_t ko_jacobian_nnz(const ko_config *c)
+{
+    int npts = 4 * c->dim + 1, F = c->nlig + 1;
+    return ko_npts(c) * ((int64_t)F * npts + (int64_t)c->nlig * (npts + 1));
+}
+
+int ko_jacobian_csr(const ko_config *c, const double *u, int64_t *rowptr, int64_t *col, double *val)
+{
+    int64_t N = ko_npts(c), nx = c->n[0], ny = c->n[1], nz = c->n[2];
+    int F = c->nlig + 1, nl = c->nlig, npts = 4 * c->dim + 1;
+    double *ug = (double *)malloc(sizeof(double) * N * (2 * F + 1));
+    if (!ug) return 1;
+    double *G = ug + (int64_t)F * N, *Gd = G + N;          /* Gd: F planes G_rho, G_U1.. */
+    memcpy(ug, u, sizeof(double) * N * F);
+    ko_groom(c, ug);
+    for (int64_t p = 0; p < N; p++) {
+        double U[KO_MAXF], GU[KO_MAXF], Gr;
+        for (int l = 0; l < nl; l++) U[l] = ug[(int64_t)(l + 1) * N + p];
+        ko_G_point(c, ug[p], U, &G[p], &Gr, GU);
+        Gd[p] = Gr;
+        for (int l = 0; l < nl; l++) Gd[(int64_t)(l + 1) * N + p] = GU[l];
+    }
+    const int64_t per = (int64_t)F * npts + (int64_t)nl * (npts + 1);
+    static const int MS[4] = { -2, -1, 1, 2 };
+    for (int64_t k = 0; k < nz; k++)
+        for (int64_t j = 0; j < ny; j++)
+            for (int64_t i = 0; i < nx; i++) {
+                int64_t p = i + nx * (j + ny * k);
+                int64_t e = p * per;
+                double d1g[3], d1r[3], lapG = 0.0, w2c = 0.0, ih[3], ih2[3];
+                int64_t q[3][4];
+                for (int ax = 0; ax < c->dim; ax++) {
+                    double h = c->L[ax] / (double)c->n[ax], d2;
+                    ih[ax] = 1.0 / h;
+                    ih2[ax] = 1.0 / (h * h);
+                    ko_d12(c, G, ax, i, j, k, &d1g[ax], &d2);
+                    lapG += d2;
+                    ko_d12(c, ug, ax, i, j, k, &d1r[ax], &d2);
+                    w2c += W2[2] * ih2[ax];
+                    for (int m = 0; m < 4; m++) {
+                        int64_t ii = i, jj = j, kk = k;
+                        if (ax == 0) ii = wrapi(i + MS[m], nx);
+                        else if (ax == 1) jj = wrapi(j + MS[m], ny);
+                        else kk = wrapi(k + MS[m], nz);
+                        q[ax][m] = ii + nx * (jj + ny * kk);
+                    }
+                }
+                const double rho0 = ug[p];
+                rowptr[p * F] = e;
+                for (int dof = 0; dof < F; dof++) {
+                    const double *Gx = Gd + (int64_t)dof * N;
+                    col[e] = p * F + dof;
+                    val[e++] = (dof == 0 ? lapG : 0.0) + rho0 * w2c * Gx[p];
+                    for (int ax = 0; ax < c->dim; ax++)
+                        for (int m = 0; m < 4; m++) {
+                            double w1 = W1[MS[m] + 2] * ih[ax], w2 = W2[MS[m] + 2] * ih2[ax];
+                            col[e] = q[ax][m] * F + dof;
+                            val[e++] = (dof == 0 ? w1 * d1g[ax] : 0.0) + (w1 * d1r[ax] + rho0 * w2) * Gx[q[ax][m]];
+                        }
+                }
+                for (int l = 0; l < nl; l++) {
+                    rowptr[p * F + l + 1] = e;
+                    col[e] = p * F;
+                    val[e++] = c->lig_s[l];
+                    col[e] = p * F + l + 1;
+                    val[e++] = -c->lig_gamma[l] + c->lig_D[l] * w2c;
+                    for (int ax = 0; ax < c->dim; ax++)
+                        for (int m = 0; m < 4; m++) {
+                            col[e] = q[ax][m] * F + l + 1;
+                            val[e++] = c->lig_D[l] * W2[MS[m] + 2] * ih2[ax];
+                        }
+                }
+            }
+    rowptr[N * F] = N * per;
+    free(ug);
+    return 0;
+}
+
 /* KSFD/ksfdsym.py:1158-1209 velocity: v_a = D1_a(G) on the groomed state; vel = dim planes. */
 int ko_velocity(const ko_config *c, const double *u, double *vel)
 {

@@ -50,6 +50,12 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
         ks.set_state(mine(u))
         got['vmax'] = ks.velocity_max()
         got['worms'] = ks.count_worms()
+        # assembled-Jacobian export: local rows, global (periodically wrapped) columns
+        import scipy.sparse as sp
+        rowptr, col, val = ks.jacobian_csr()
+        A = sp.csr_matrix((val, col, rowptr), shape=(rowptr.size - 1, cfg.F * N))
+        loc = (A @ v.reshape(cfg.F, N).T.reshape(-1)).reshape(-1, cfg.F).T.reshape(-1)
+        got['csr_jv'] = gather_slabs(loc, cfg)
         opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
         t, h = 0.0, 0.02
         stats = []
@@ -66,6 +72,7 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
         if rank == 0:
             one = klib.KSFDHip(cfg)
             ref = {'rhs': one.rhs(u), 'jvp': one.jvp(v, u)}
+            ref['csr_jv'] = ref['jvp']
             one.set_state(u)
             ref['vmax'] = one.velocity_max()
             ref['worms'] = one.count_worms()
@@ -87,7 +94,7 @@ def _run(size, shape, nlig, transport, tmp_path):
     z = np.load(outfile)
     if 'skip' in z:
         pytest.skip('transport %s unavailable here: %s' % (transport, z['skip']))
-    for k in ('rhs', 'jvp'):
+    for k in ('rhs', 'jvp', 'csr_jv'):
         assert rel_l2(z['got_' + k], z['ref_' + k]) < 1e-11, k
     assert rel_l2(z['got_state'], z['ref_state']) < 1e-9          # includes one h=5 step solved to ksp_rtol=1e-11
     if len(shape) == 2 or shape == (16, 16, 32):

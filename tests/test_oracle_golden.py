@@ -22,6 +22,67 @@ def test_oracle_operators(name):
     assert rel_l2(o.jvp(u, cijk_to_soa(z['v'])), cijk_to_soa(z['Jv'])) < OP_TOL
 
 
+def golden_entry_fields(z, cfg):
+    """reference Jacobian entries as a dict (row_dof, di, dj, dk, col_dof) -> (nx,ny,nz) field (U rows: constants)"""
+    S = tuple(int(x) for x in cfg.n[:cfg.dim])
+    out = {}
+    for off, val in zip(z['Jrho_off'], z['Jrho_val']):
+        out[(0, int(off[0]), int(off[1]), int(off[2]), int(off[3]))] = np.asarray(val).reshape(S)
+    for r, off, val in zip(z['JU_row'], z['JU_off'], z['JU_val']):
+        out[(int(r), int(off[0]), int(off[1]), int(off[2]), int(off[3]))] = np.full(S, float(val))
+    return out
+
+
+def csr_entry_fields(cfg, rowptr, col, val):
+    """the same dict from a CSR in the reference's Vec ordering (row = F*p + dof, p x-fastest)"""
+    F, dim = cfg.nlig + 1, cfg.dim
+    n = [int(x) for x in cfg.n[:3]]
+    S = tuple(n[:dim])
+    out = {}
+    rows = np.repeat(np.arange(rowptr.size - 1), np.diff(rowptr))
+    rp, rd = rows // F, rows % F
+    cp, cd = col // F, col % F
+    d = []
+    for a, stride in enumerate((1, n[0], n[0] * n[1])):
+        ra, ca = (rp // stride) % n[a], (cp // stride) % n[a]
+        da = (ca - ra + n[a] // 2) % n[a] - n[a] // 2            # periodic offset in (-n/2, n/2]
+        d.append(da)
+    keys = np.stack([rd, d[0], d[1], d[2], cd], axis=1)
+    for key in np.unique(keys, axis=0):
+        sel = np.all(keys == key, axis=1)
+        f = np.zeros(int(np.prod(S)))
+        np.add.at(f, rp[sel], val[sel])
+        out[tuple(int(x) for x in key)] = f.reshape(S, order='F')
+    return out
+
+
+@pytest.mark.parametrize('name', golden_cases('op_'))
+def test_oracle_assembled_jacobian_entries(name):
+    """every entry field of the reference's assembled Jacobian (rho rows: KSFD/ksfdsym.py:675-761,1067-1127; U rows
+    :630-673) against the oracle's CSR; and CSR @ v == the matrix-free action"""
+    import scipy.sparse as sp
+    z = load_golden(name)
+    cfg = ProblemConfig.from_golden(z)
+    o = ko.Oracle(cfg)
+    u = cijk_to_soa(z['u'])
+    rowptr, col, val = o.jacobian_csr(u)
+    ref = golden_entry_fields(z, cfg)
+    got = csr_entry_fields(cfg, rowptr, col, val)
+    scale = max(np.abs(f).max() for f in ref.values())
+    for key, f in ref.items():
+        if key not in got:
+            assert np.abs(f).max() <= 1e-13 * scale, key          # the reference lists structurally zero entries too
+            continue
+        assert np.abs(got[key] - f).max() <= 1e-12 * max(np.abs(f).max(), 1e-300) + 1e-15 * scale, key
+    for key, f in got.items():
+        assert key in ref or np.abs(f).max() <= 1e-13 * scale, key
+    F, N = cfg.nlig + 1, o.N
+    A = sp.csr_matrix((val, col, rowptr), shape=(F * N, F * N))
+    v = cijk_to_soa(z['v']).reshape(F, N)
+    Jv = (A @ v.T.reshape(-1)).reshape(N, F).T.reshape(-1)       # PETSc (dof fastest) <-> SoA
+    assert rel_l2(Jv, cijk_to_soa(z['Jv'])) < 1e-12
+
+
 @pytest.mark.parametrize('name', golden_cases('op_'))
 def test_oracle_groom_active(name):
     """inputs with negatives, sub-floor values and NaNs (KSFD/ksfdsym.py:888-900)"""
