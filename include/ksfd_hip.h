@@ -183,6 +183,9 @@ int ksfd_synchronize(ksfd_handle *h);
 int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms, double *bytes_per_launch);
 /* use_fused: bit0 fused kernels, bit1 set = recompute (non-frozen) Jacobian action, bit2 set = no halo/compute overlap,
  * bit3 set = pipelined GMRES with device-resident Hessenberg/Givens state (off by default);
+ * bit4 set = no Krylov recycling across the four stage systems of a step, bit5 set = recycle from every earlier stage
+ * (default: from the stages measured to matter: 1 for 2 and 3, 1 and 3 for 4), bits 6-8 = leading Arnoldi vectors kept
+ * per stage (1..4, 0 keeps the default 3);
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

@@ -108,6 +108,13 @@ struct ksfd_handle {
     double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
 
+    // Krylov recycling across the four stage systems of one step (same matrix): see gmres()
+    struct RecSpace { bool valid = false; int vb = 0, zb = 0, k = 0, pc = 0; double H[20]; };   // leading (k+1) x k raw Hessenberg, ld = k+1
+    RecSpace rec[4];
+    int rec_vtop = 0, rec_ztop = 0;  // first free slot of V / Zb behind the kept vectors
+    int rec_mode = 1;                // 0 off, 1 selected earlier stages (default), 2 every earlier stage
+    int rec_keep = 3;                // leading vectors kept per stage (<= 4)
+
     // multigrid preconditioner
     std::vector<MGLevel> mg;
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
@@ -1372,8 +1379,52 @@ static int poly_apply(ksfd_handle *h, double shift, double *v, double *z)
 // ------------------------------------------------------------------------------------------------
 struct LinStats { int its; double rel; };
 
+static void rec_reset(ksfd_handle *h)
+{
+    for (auto &r : h->rec) r.valid = false;
+    h->rec_vtop = h->rec_ztop = 0;
+}
+
+// Least squares min ||g - H y|| for a small upper-Hessenberg H ((k+1) x k, column-major, ld = k+1); also returns H y.
+static void hess_lsq(const double *H, int k, const double *g, double *y, double *Hy)
+{
+    double R[20], q[5];
+    const int ld = k + 1;
+    for (int i = 0; i < ld * k; i++) R[i] = H[i];
+    for (int i = 0; i <= k; i++) q[i] = g[i];
+    for (int j = 0; j < k; j++) {
+        const double a = R[j * ld + j], b = R[j * ld + j + 1], den = hypot(a, b);
+        const double c = den > 0.0 ? a / den : 1.0, sn = den > 0.0 ? b / den : 0.0;
+        for (int l = j; l < k; l++) {
+            const double t = c * R[l * ld + j] + sn * R[l * ld + j + 1];
+            R[l * ld + j + 1] = -sn * R[l * ld + j] + c * R[l * ld + j + 1];
+            R[l * ld + j] = t;
+        }
+        const double t = c * q[j] + sn * q[j + 1];
+        q[j + 1] = -sn * q[j] + c * q[j + 1];
+        q[j] = t;
+    }
+    for (int i = k - 1; i >= 0; i--) {
+        double t = q[i];
+        for (int l = i + 1; l < k; l++) t -= R[l * ld + i] * y[l];
+        y[i] = R[i * ld + i] != 0.0 ? t / R[i * ld + i] : 0.0;
+    }
+    for (int i = 0; i <= k; i++) {
+        double t = 0.0;
+        for (int l = 0; l < k; l++) t += H[l * ld + i] * y[l];
+        Hy[i] = t;
+    }
+}
+
+// stage >= 0: Krylov recycling.  The four stage systems of a step share the matrix, and their right-hand sides are
+// nearly linear images of one another (b_i = f(u + sum a_ij Y_j) - sum c_ij Y_j/h with f almost linear over a step), so
+// the leading Arnoldi vectors of an earlier stage (A Z_s = V_s H_s, kept in place at the front of V / Zb) already span
+// most of the new solution: x0 = Z_s y with y = argmin ||V_s^T r - H_s y||, r <- r - V_s H_s y, one space after the
+// other, costs ~5 vector passes per kept vector and removes 1-2 of the 3-4 outer iterations of stages 2-4 (each
+// (d+1) Jacobian actions + Gram-Schmidt).  The iteration then continues on the true residual with the same stopping
+// test, so the result is the same to the solver tolerance.  stage < 0: plain solve from x0 = 0.
 static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
-                 const ksfd_step_opts *o, LinStats *ls, int pcmode)
+                 const ksfd_step_opts *o, LinStats *ls, int pcmode, int stage = -1)
 {
     const bool use_pc = pcmode == 1;       // multigrid, right preconditioning
     const bool use_poly = pcmode == 2;     // Chebyshev polynomial, flexible GMRES (z_j kept in Zb)
@@ -1381,12 +1432,17 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     auto apply_A = [&](const double *vin, double *wout) -> int {
         return h->use_frozen ? op_jvp_frozen(h, vin, 1, shift, wout) : op_jvp(h, ustate, vin, 1, shift, wout);
     };
-    const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
+    const int m_opt = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
     const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
     const int64_t vs = h->vlen;
-    double *V = h->V;
+    bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen;
+    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 10) { if (stage != 0) rec_on = false; rec_reset(h); }
+    const int vb = rec_on ? h->rec_vtop : 0, zb = rec_on ? h->rec_ztop : 0;
+    const int m = std::min(m_opt, h->restart_alloc - vb);
+    double *V = h->V + (int64_t)vb * vs;
+    double *Zq = use_poly ? h->Zb + (int64_t)zb * vs : nullptr;
     int rc;
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2), Gm((size_t)(m + 1) * (m + 1), 0.0);
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), Hraw((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2), Gm((size_t)(m + 1) * (m + 1), 0.0);
     if ((rc = op_multidot(h, b, V, 0))) return rc;
     const double bn = sqrt(h->hres[0]);
     ls->its = 0; ls->rel = 0.0;
@@ -1398,10 +1454,47 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
     double beta = bn, rn = bn;
     int total = 0;
-    bool first = true;
+    bool first = true;          // the residual of the current x is at hand (rsrc, norm beta): no A x needed
+    bool x_set = false;         // x holds an iterate (else it is taken as 0 and overwritten)
+    bool restarted = false;
+    const double *rsrc = b;
+    if (rec_on && stage > 0) {
+        static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
+        for (int q = 0; q < stage; q++) {
+            bool use = h->rec_mode == 2;
+            for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
+            const ksfd_handle::RecSpace &S = h->rec[q];
+            if (!use || !S.valid || S.pc != pcmode) continue;
+            const double *Vs = h->V + (int64_t)S.vb * vs;
+            const double *Zs = use_poly ? h->Zb + (int64_t)S.zb * vs : Vs;
+            double gq[5], yq[4], Hy[5], neg[5];
+            if ((rc = op_multidot(h, rsrc, Vs, S.k + 1))) return rc;
+            for (int i = 0; i <= S.k; i++) gq[i] = h->hres[i];
+            hess_lsq(S.H, S.k, gq, yq, Hy);
+            if (use_pc) {
+                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
+                if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
+                else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
+            } else if ((rc = op_basis_axpy(h, x, Zs, S.k, yq, x_set ? 1.0 : 0.0))) return rc;
+            x_set = true;
+            for (int i = 0; i <= S.k; i++) neg[i] = -Hy[i];
+            if (rsrc == b) {
+                const double *xs[6] = { b }; double a[6] = { 1.0 };
+                for (int i = 0; i <= S.k; i++) { xs[i + 1] = Vs + (int64_t)i * vs; a[i + 1] = neg[i]; }
+                if ((rc = op_lincomb(h, S.k + 2, xs, a, h->t3))) return rc;
+                rsrc = h->t3;
+            } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0))) return rc;
+        }
+        if (x_set) {
+            if ((rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
+            beta = rn = sqrt(h->hres[0]);
+            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: projected residual is not finite");
+        }
+    }
     while (true) {
+        if (first && beta <= tol) break;                       // the recycled spaces already hold the solution
         // V0 = r / beta
-        if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
+        if (first) { const double *xs[1] = { rsrc }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
         else {
             if ((rc = halo(h, x)) || (rc = apply_A(x, V))) return rc;     // V0 = A x
             const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
@@ -1423,7 +1516,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             if (use_pc) {
                 if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
             } else if (use_poly) {
-                double *zj = h->Zb + (int64_t)j * vs;
+                double *zj = Zq + (int64_t)j * vs;
                 if ((rc = poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
             } else if (h->use_frozen) {
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
@@ -1484,7 +1577,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 hcol[k] = hn;
             }
             double *Hc = &H[(size_t)(m + 1) * j];
-            for (int i = 0; i <= k; i++) Hc[i] = hcol[i];
+            for (int i = 0; i <= k; i++) Hraw[(size_t)(m + 1) * j + i] = Hc[i] = hcol[i];
             for (int i = 0; i < j; i++) { double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1]; Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1]; Hc[i] = t; }
             const double den = hypot(Hc[j], Hc[j + 1]);
             cs[j] = den > 0.0 ? Hc[j] / den : 1.0;
@@ -1503,12 +1596,27 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         }
         if (use_pc) {
             if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
-            if (first) { if ((rc = op_copy(h, x, h->t1))) return rc; }
+            if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
             else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
-        } else if ((rc = op_basis_axpy(h, x, use_poly ? h->Zb : V, j, y.data(), first ? 0.0 : 1.0))) return rc;
+        } else if ((rc = op_basis_axpy(h, x, use_poly ? Zq : V, j, y.data(), x_set ? 1.0 : 0.0))) return rc;
+        x_set = true;
+        if (rec_on && first && !restarted && done && j >= 1) {
+            // keep the leading vectors of this stage's Arnoldi relation where they are; the next stage builds behind them
+            ksfd_handle::RecSpace &S = h->rec[stage];
+            S.k = std::min(j, std::min(h->rec_keep, 4));
+            S.vb = vb; S.zb = zb; S.pc = pcmode;
+            for (int c = 0; c < S.k; c++)
+                for (int i = 0; i <= S.k; i++) S.H[c * (S.k + 1) + i] = Hraw[(size_t)(m + 1) * c + i];
+            S.valid = true;
+            h->rec_vtop = vb + S.k + 1;
+            h->rec_ztop = zb + (use_poly ? S.k : 0);
+        }
+        if (!first) restarted = true;
         first = false;
         if (done || total >= maxit) break;
+        restarted = true;
     }
+    if (!x_set) HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
     ls->its = total;
     ls->rel = rn / bn;
     if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
@@ -1525,6 +1633,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
 // ------------------------------------------------------------------------------------------------
 static int gmres_async(ksfd_handle *h, double shift, const double *b, double *x, const ksfd_step_opts *o, LinStats *ls)
 {
+    rec_reset(h);
     const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
     const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
     const int64_t vs = h->vlen;
@@ -1726,7 +1835,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             LinStats ls;
             rc = use_async ? gmres_async(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls)
-                           : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0));
+                           : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0), i);
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
             if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
@@ -1866,6 +1975,8 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
     if (use_fused >= 0) {
         h->use_fused = use_fused & 1; h->use_frozen = !(use_fused & 2); h->overlap = !(use_fused & 4);
         h->async_mode = (use_fused & 8) ? 1 : 0;
+        h->rec_mode = (use_fused & 16) ? 0 : ((use_fused & 32) ? 2 : 1);
+        if ((use_fused >> 6) & 7) h->rec_keep = std::min((use_fused >> 6) & 7, 4);
     }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;

@@ -242,3 +242,30 @@ def test_failed_linear_solve_falls_back():
     t, hn, st, rc = k.step(0.0, 0.02, o, raise_on_error=False)
     assert rc == klib.ELINEAR and not st.accepted and np.array_equal(k.get_state(), ko.Oracle(cfg).groom(u))
     k.close()
+
+
+def test_krylov_recycling_across_stages_saves_iterations_same_answer():
+    """the four stage systems of a step share the matrix: projecting each new right-hand side onto the kept leading
+    Arnoldi vectors of earlier stages (gmres(), stage >= 0) removes outer iterations and changes the result only
+    within the solver tolerance; with a tight tolerance both variants equal the oracle's step"""
+    n = 64
+    cfg = ProblemConfig.standard(2, (n, n), L=(n * 4.0 / 1536, n * 4.0 / 1536), nlig=1)
+    rng = np.random.default_rng(17)
+    rho = 9000 + 90 * rng.standard_normal(n * n)
+    u = np.concatenate([rho, rho])
+    h = 0.02                                                    # h*gamma*lambda_max ~ 4: polynomial-preconditioned regime
+    un, _, _, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=1e-13, maxit=2000)   # dense LU would take minutes here
+    k = klib.KSFDHip(cfg)
+    res = {}
+    for name, tune in (('on', 1), ('off', 1 | 16), ('all', 1 | 32)):
+        k.set_tuning(use_fused=tune)
+        for tol in (1e-6, 1e-11):
+            k.set_state(u)
+            t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=tol))
+            res[name, tol] = (st.linear_its, k.get_state())
+    assert res['on', 1e-6][0] < res['off', 1e-6][0], (res['on', 1e-6][0], res['off', 1e-6][0])
+    assert res['on', 1e-11][0] < res['off', 1e-11][0]
+    for name in ('on', 'off', 'all'):
+        assert rel_l2(res[name, 1e-11][1], un) < 1e-10, name
+        assert rel_l2(res[name, 1e-6][1], un) < 1e-7, name
+    k.close()
