@@ -59,8 +59,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ksfd_amd import lib as klib
-    from ksfd_amd.dist import open_handle, local_slab
-    from ksfd_amd.initial import start_values
+    from ksfd_amd.dist import open_handle
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -82,7 +81,6 @@ def main():
             dist.init_process_group('gloo')
 
     cfg = build_problem(args.n, args.nlig, dim=args.dim)
-    u0 = start_values(cfg)                                  # global SoA state (identical on every rank)
     ks, keep = open_handle(cfg, rank, world, dev, transport=args.transport, group=None, host_group=host_group)
     if args.yseg:
         ks.set_tuning(yseg=args.yseg)
@@ -90,8 +88,10 @@ def main():
         ks.set_poly_params(int(os.environ['KSFD_POLY_DEG']), float(os.environ.get('KSFD_POLY_TARGET', '0')))
     if os.environ.get('KSFD_TUNE'):                      # A/B switches of ksfd_set_tuning (tools/async_bench.py)
         ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
-    ks.set_state(local_slab(u0, cfg, rank, world) if world > 1 else u0)
-    del u0
+    # synthetic start values of SURVEY.md 8d, interpolated on the device slab by slab from the global coarse samples
+    # (seed 793817931, n/4 coarse normal noise sigma=90 around rho=9000, U = rho*s/gamma): ksfd_set_state_random
+    from ksfd_amd.initial import reference_rng
+    ks.set_state_random(reference_rng().normal(size=tuple(max(1, n // 4) for n in cfg.n[:cfg.dim])) * 90.0, 9000.0)
 
     if args.fixed_h > 0:
         opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=args.ksp_rtol)

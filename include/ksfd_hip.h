@@ -133,6 +133,11 @@ int64_t ksfd_local_size(const ksfd_handle *h);               /* F * local points
 /* -- state (the TS solution Vec u; KSFD/ksfdts.py:141-152).  Host buffers hold the LOCAL slab. */
 int ksfd_set_state(ksfd_handle *h, const double *u_host, int32_t layout);
 int ksfd_get_state(ksfd_handle *h, double *u_host, int32_t layout);
+/* "next" row f3: the reference's start_values (ksfdsolver2.py:580-639) evaluated on the device for this rank's slab:
+ * rho = rho0 + smoothstep interpolation (KSFD/ksfdrandom.py:116,194-214) of the coarse samples z (GLOBAL coarse grid
+ * nc[0..2], x fastest, periodic; the caller draws them from numpy's default_rng so the stream matches ksfdrandom.py:44-49),
+ * U_l = rho*s_l/gamma_l (:636-637). */
+int ksfd_set_state_random(ksfd_handle *h, const int64_t nc[3], const double *z_coarse_host, double rho0);
 double *ksfd_device_state(ksfd_handle *h);      /* device pointer, SoA with ghost rows; plane stride below */
 int64_t ksfd_device_plane_stride(const ksfd_handle *h);
 int64_t ksfd_device_interior_offset(const ksfd_handle *h);

@@ -751,6 +751,31 @@ extern "C" int ksfd_set_state(ksfd_handle *h, const double *u, int32_t layout)
     HIPCHK(h, hipStreamSynchronize(h->st));
     return KSFD_OK;
 }
+extern "C" int ksfd_set_state_random(ksfd_handle *h, const int64_t *nc, const double *z, double rho0)
+{
+    if (!h || !nc || !z) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    int64_t n = 1;
+    for (int a = 0; a < 3; a++) {
+        if (a < h->G.dim ? nc[a] < 1 : nc[a] != 1) return fail(h, KSFD_EINVAL, "coarse grid must be >= 1 per used axis and 1 elsewhere");
+        n *= nc[a];
+    }
+    double *dz = nullptr;
+    if (hipMalloc((void **)&dz, sizeof(double) * (size_t)n) != hipSuccess) return fail(h, KSFD_ENOMEM, "hipMalloc of the coarse samples failed");
+    hipError_t e = hipMemcpyAsync(dz, z, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->st);
+    const KGeom &G = h->G;
+    int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 65535);
+    if (e == hipSuccess) {
+        Scope sc(h, KC_MISC, vbytes(h, 1));
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_random_start<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (long long)h->cfg.n[G.dim - 1],
+                                                  (long long)h->slow0, (long long)nc[0], (long long)nc[1], (long long)nc[2], (const double *)dz, rho0, h->u));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    hipFree(dz);
+    if (e != hipSuccess) return fail(h, KSFD_EHIP, "random start: %s", hipGetErrorString(e));
+    return KSFD_OK;
+}
 extern "C" int ksfd_get_state(ksfd_handle *h, double *u, int32_t layout)
 {
     if (!h || !u) return KSFD_EINVAL;
@@ -1949,7 +1974,7 @@ extern "C" int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_ma
     if (power_its > 0) h->mg_power_its = power_its;
     if (ratio > 1.0) h->mg_ratio = ratio;
     if (coarse_tol > 0.0) h->mg_coarse_tol = coarse_tol;
-    h->mg_use_graph = power_its != -7;     // power_its = -7: eager launches (debug / A-B timing)
+    h->mg_use_graph = power_its != -7 && h->size == 1;     // power_its = -7: eager launches (debug / A-B timing); slab ranks: collectives inside the cycle
     h->mg_shift = -1.0;
     return KSFD_OK;
 }

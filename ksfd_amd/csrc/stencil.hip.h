@@ -189,6 +189,52 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
     }
 }
 
+// Synthetic start values on the device (ksfdsolver2.py:580-639): rho = rho0 + smoothstep
+// interpolation of the coarse samples z (KSFD/ksfdrandom.py:116, 194-214: weight f(x) = 2x^3 - 3x^2 + 1 on
+// |dx|/h_coarse < 1 per axis, periodic; f(x) + f(1-x) = 1, so each fine point is a convex combination of its 2^dim coarse
+// neighbours), U_l = rho * s_l / gamma_l.  z: global coarse grid, x fastest.  Same summation order as the oracle.
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_random_start(KGeom G, KPhys P, long long gslow, long long slow0,
+                                                             long long nc0, long long nc1, long long nc2,
+                                                             const double *__restrict__ z, double rho0, double *__restrict__ u)
+{
+    const int slow = G.dim - 1;
+    const long long nc[3] = { nc0, nc1, nc2 };
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
+        long long idx[3];
+        ksfd_decode(G, p, idx[0], idx[1], idx[2]);
+        idx[slow] += slow0;
+        const long long gext[3] = { slow == 0 ? gslow : G.nx, slow == 1 ? gslow : G.ny, slow == 2 ? gslow : G.nz };
+        long long lo[3] = { 0, 0, 0 };
+        double wlo[3] = { 1.0, 1.0, 1.0 }, whi[3] = { 0.0, 0.0, 0.0 };
+        for (int a = 0; a < G.dim; a++) {
+            const double xc = (double)idx[a] * (double)nc[a] / (double)gext[a];
+            const double fl = floor(xc), fr = xc - fl, g1 = 1.0 - fr;
+            lo[a] = (long long)fl;
+            wlo[a] = 2.0 * fr * fr * fr - 3.0 * fr * fr + 1.0;
+            whi[a] = fr == 0.0 ? 0.0 : 2.0 * g1 * g1 * g1 - 3.0 * g1 * g1 + 1.0;
+        }
+        double sum = 0.0;
+        for (int dz = 0; dz < (G.dim > 2 ? 2 : 1); dz++)
+            for (int dy = 0; dy < (G.dim > 1 ? 2 : 1); dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                    const double w = (dx ? whi[0] : wlo[0]) * (G.dim > 1 ? (dy ? whi[1] : wlo[1]) : 1.0) *
+                                     (G.dim > 2 ? (dz ? whi[2] : wlo[2]) : 1.0);
+                    if (w == 0.0) continue;
+                    const long long ci = ksfd_wrap(lo[0] + dx, nc[0]);
+                    const long long cj = G.dim > 1 ? ksfd_wrap(lo[1] + dy, nc[1]) : 0;
+                    const long long ck = G.dim > 2 ? ksfd_wrap(lo[2] + dz, nc[2]) : 0;
+                    sum += w * z[ci + nc[0] * (cj + nc[1] * ck)];
+                }
+        const long long o = (long long)G.ng * G.inner + p;
+        const double rho = rho0 + sum;
+        u[o] = rho;
+#pragma unroll
+        for (int l = 0; l < NL; l++) u[(long long)(l + 1) * G.plane + o] = rho * (P.lig_s[l] / P.lig_gamma[l]);
+    }
+}
+
 // Assembled Jacobian export: what Derivatives.Jacobian + ksfdMat.setValuesJacobian put
 // into the PETSc AIJ matrix (KSFD/ksfdsym.py:814-886, cython/ksfdMat/ksfdMat.pyx:55-180), as CSR values + GLOBAL column
 // indices in the reference's Vec ordering (unknown = F*point + dof, point x-fastest).  One thread per owned point,

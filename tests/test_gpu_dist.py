@@ -50,6 +50,11 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
         ks.set_state(mine(u))
         got['vmax'] = ks.velocity_max()
         got['worms'] = ks.count_worms()
+        # start values generated on the device, slab by slab, from the global coarse samples
+        zc = np.random.default_rng(5).normal(size=tuple(max(1, n // 4) for n in shape)) * 90.0
+        ks.set_state_random(zc, 9000.0)
+        got['start'] = gather_slabs(ks.get_state(), cfg)
+        ks.set_state(mine(u))
         # assembled-Jacobian export: local rows, global (periodically wrapped) columns
         import scipy.sparse as sp
         rowptr, col, val = ks.jacobian_csr()
@@ -73,6 +78,8 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
             one = klib.KSFDHip(cfg)
             ref = {'rhs': one.rhs(u), 'jvp': one.jvp(v, u)}
             ref['csr_jv'] = ref['jvp']
+            one.set_state_random(np.random.default_rng(5).normal(size=tuple(max(1, n // 4) for n in shape)) * 90.0, 9000.0)
+            ref['start'] = one.get_state()
             one.set_state(u)
             ref['vmax'] = one.velocity_max()
             ref['worms'] = one.count_worms()
@@ -94,6 +101,7 @@ def _run(size, shape, nlig, transport, tmp_path):
     z = np.load(outfile)
     if 'skip' in z:
         pytest.skip('transport %s unavailable here: %s' % (transport, z['skip']))
+    assert np.array_equal(z['got_start'], z['ref_start'])
     for k in ('rhs', 'jvp', 'csr_jv'):
         assert rel_l2(z['got_' + k], z['ref_' + k]) < 1e-11, k
     assert rel_l2(z['got_state'], z['ref_state']) < 1e-9          # includes one h=5 step solved to ksp_rtol=1e-11

@@ -183,3 +183,26 @@ def test_assembled_jacobian_direct_solve_reproduces_the_reference_style_step():
     r = shift * ysoa - k.jvp(ysoa) - f
     assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(f)
     k.close()
+
+
+@pytest.mark.parametrize('shape,nlig,coarse', [((64, 48), 1, None), ((36, 20), 2, (5, 7)), ((16, 12, 20), 1, None), ((96,), 1, (10,)),
+                                               ((37, 21), 1, (37, 4))])
+def test_device_start_values_vs_oracle_and_host_generator(shape, nlig, coarse):
+    """ksfd_set_state_random (row f3) vs the oracle's ko_random_function and vs ksfd_amd.initial.start_values"""
+    from ksfd_amd.initial import start_values, reference_rng
+    dim = len(shape)
+    cfg = ProblemConfig.standard(dim, shape, L=[0.3] * dim, nlig=nlig)
+    coarse = tuple(coarse) if coarse else tuple(max(1, s // 4) for s in shape)
+    z = reference_rng().normal(size=coarse) * 90.0
+    k = klib.KSFDHip(cfg)
+    k.set_state_random(z, rho0=9000.0)
+    got = k.get_state()
+    N = cfg.N
+    nc = list(coarse) + [1] * (3 - dim)
+    want_rho = 9000.0 + ko.Oracle(cfg).random_function(nc, z.ravel(order='F'))
+    assert np.abs(got[:N] - want_rho).max() <= 1e-13 * 9000.0
+    for l in range(nlig):
+        assert np.allclose(got[(l + 1) * N:(l + 2) * N], got[:N] * (cfg.lig_s[l] / cfg.lig_gamma[l]), rtol=1e-15, atol=0)
+    host = start_values(cfg, coarse=coarse)
+    assert rel_l2(got, host) < 1e-14
+    k.close()
