@@ -133,6 +133,13 @@ int64_t ksfd_local_size(const ksfd_handle *h);               /* F * local points
 /* -- state (the TS solution Vec u; KSFD/ksfdts.py:141-152).  Host buffers hold the LOCAL slab. */
 int ksfd_set_state(ksfd_handle *h, const double *u_host, int32_t layout);
 int ksfd_get_state(ksfd_handle *h, double *u_host, int32_t layout);
+/* "next" row f2: asynchronous read-out for writers (TimeSeries.store / makeSaveMonitor, KSFD/ksfdtimeseries.py:484-509,
+ * KSFD/ksfdts.py:466-497) -- the layout transform is ordered on the compute stream, the D2H copy runs on a third stream
+ * into one of two pinned buffers owned by the handle while the stepper carries on.  _wait blocks until the copy has landed
+ * and returns the buffer (ksfd_local_size doubles), valid until the second-next _begin.  Thread rule: _begin from the
+ * stepping thread; _wait may be called from a writer thread. */
+int ksfd_snapshot_begin(ksfd_handle *h, int32_t layout, int32_t *slot);
+int ksfd_snapshot_wait(ksfd_handle *h, int32_t slot, const double **host);
 /* "next" row f3: the reference's start_values (ksfdsolver2.py:580-639) evaluated on the device for this rank's slab:
  * rho = rho0 + smoothstep interpolation (KSFD/ksfdrandom.py:116,194-214) of the coarse samples z (GLOBAL coarse grid
  * nc[0..2], x fastest, periodic; the caller draws them from numpy's default_rng so the stream matches ksfdrandom.py:44-49),

@@ -108,6 +108,14 @@ struct ksfd_handle {
     double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
 
+    // asynchronous snapshots for writers (ksfd_snapshot_begin / _wait): layout transform on the compute stream into a
+    // device staging slot, D2H on a third stream into pinned memory while the stepper carries on
+    hipStream_t st_io = nullptr;
+    double *snap_dev[2] = { nullptr, nullptr }, *snap_host[2] = { nullptr, nullptr };
+    hipEvent_t snap_ready[2] = { nullptr, nullptr }, snap_done[2] = { nullptr, nullptr };
+    bool snap_busy[2] = { false, false };
+    int snap_next = 0;
+
     // Krylov recycling across the four stage systems of one step (same matrix): see gmres()
     struct RecSpace { bool valid = false; int vb = 0, zb = 0, k = 0, pc = 0; double H[20]; };   // leading (k+1) x k raw Hessenberg, ld = k+1
     RecSpace rec[4];
@@ -608,6 +616,13 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     for (auto e : h->gm_ev) if (e) hipEventDestroy(e);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
+    if (h->st_io) { hipStreamSynchronize(h->st_io); hipStreamDestroy(h->st_io); }
+    for (int q = 0; q < 2; q++) {
+        if (h->snap_dev[q]) hipFree(h->snap_dev[q]);
+        if (h->snap_host[q]) hipHostFree(h->snap_host[q]);
+        if (h->snap_ready[q]) hipEventDestroy(h->snap_ready[q]);
+        if (h->snap_done[q]) hipEventDestroy(h->snap_done[q]);
+    }
     mg_free(h);
     delete h->tr;
     if (h->ev_ready) hipEventDestroy(h->ev_ready);
@@ -751,6 +766,55 @@ extern "C" int ksfd_set_state(ksfd_handle *h, const double *u, int32_t layout)
     HIPCHK(h, hipStreamSynchronize(h->st));
     return KSFD_OK;
 }
+// Asynchronous read-out of the resident state for writers ("next" row f2: TimeSeries fed from the device without
+// stalling the stepper).  _begin: the layout transform runs on the compute stream (ordered after everything issued so
+// far, ~0.1 ms at 4096^2) into one of two device staging slots; the D2H copy into pinned memory runs on a third stream.
+// _wait: blocks until that copy has landed and hands out the pinned buffer (F*nlocal doubles), valid until the slot is
+// used again, i.e. until the second-next _begin.  A slot whose data nobody waited for is simply overwritten.
+extern "C" int ksfd_snapshot_begin(ksfd_handle *h, int32_t layout, int32_t *slot)
+{
+    if (!h || !slot) return KSFD_EINVAL;
+    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
+    hipSetDevice(h->device);
+    const KGeom &G = h->G;
+    const size_t bytes = sizeof(double) * (size_t)G.F * G.nloc;
+    if (!h->st_io) {
+        if (hipStreamCreateWithFlags(&h->st_io, hipStreamNonBlocking) != hipSuccess) return fail(h, KSFD_EHIP, "hipStreamCreate (io) failed");
+        for (int q = 0; q < 2; q++) {
+            if (hipMalloc((void **)&h->snap_dev[q], bytes) != hipSuccess || hipHostMalloc((void **)&h->snap_host[q], bytes, hipHostMallocDefault) != hipSuccess)
+                return fail(h, KSFD_ENOMEM, "snapshot staging buffers (%zu bytes each) could not be allocated", bytes);
+            if (hipEventCreateWithFlags(&h->snap_ready[q], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->snap_done[q], hipEventDisableTiming) != hipSuccess) return fail(h, KSFD_EHIP, "hipEventCreate failed");
+        }
+    }
+    const int q = h->snap_next;
+    h->snap_next ^= 1;
+    if (h->snap_busy[q]) HIPCHK(h, hipEventSynchronize(h->snap_done[q]));      // its previous copy must have left the staging slot
+    {
+        Scope sc(h, KC_MISC, vbytes(h, 2));
+        hipLaunchKernelGGL(k_to_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, (const double *)h->u, G.plane,
+                           (long long)G.ng * G.inner, h->snap_dev[q]);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->snap_ready[q], h->st));
+    HIPCHK(h, hipStreamWaitEvent(h->st_io, h->snap_ready[q], 0));
+    HIPCHK(h, hipMemcpyAsync(h->snap_host[q], h->snap_dev[q], bytes, hipMemcpyDeviceToHost, h->st_io));
+    HIPCHK(h, hipEventRecord(h->snap_done[q], h->st_io));
+    h->snap_busy[q] = true;
+    *slot = q;
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_snapshot_wait(ksfd_handle *h, int32_t slot, const double **host)
+{
+    if (!h || !host || slot < 0 || slot > 1) return KSFD_EINVAL;
+    if (!h->snap_busy[slot]) return fail(h, KSFD_EINVAL, "snapshot slot %d holds nothing", slot);
+    hipSetDevice(h->device);
+    HIPCHK(h, hipEventSynchronize(h->snap_done[slot]));
+    *host = h->snap_host[slot];
+    return KSFD_OK;
+}
+
 extern "C" int ksfd_set_state_random(ksfd_handle *h, const int64_t *nc, const double *z, double rho0)
 {
     if (!h || !nc || !z) return KSFD_EINVAL;

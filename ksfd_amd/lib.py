@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     'ksfd_kernel_class_name', 'ksfd_rccl_unique_id', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
     'ksfd_local_range', 'ksfd_local_size', 'ksfd_set_state', 'ksfd_get_state', 'ksfd_device_state',
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
-    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr', 'ksfd_set_state_random',
+    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr', 'ksfd_set_state_random', 'ksfd_snapshot_begin', 'ksfd_snapshot_wait',
     'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
     'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params', 'ksfd_set_poly_params',
 ]
@@ -110,6 +110,8 @@ def load():
     L.ksfd_count_worms.argtypes = [vp, dp]
     L.ksfd_scale_rho.argtypes = [vp, C.c_double]
     L.ksfd_mul_rho.argtypes = [vp, dp]
+    L.ksfd_snapshot_begin.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
+    L.ksfd_snapshot_wait.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(C.c_double))]
     L.ksfd_set_state_random.argtypes = [vp, C.POINTER(C.c_int64), dp, C.c_double]
     L.ksfd_jacobian_nnz.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ksfd_jacobian_csr.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp]
@@ -254,6 +256,18 @@ class KSFDHip:
     def mul_rho(self, factor):
         f = self._vec(factor, self.nlocal // self.F)
         self._chk(self.L.ksfd_mul_rho(self.h, _dp(f)))
+
+    def snapshot_begin(self, layout=SOA):
+        """start an asynchronous copy of the state to pinned host memory; returns the slot to pass to snapshot_wait"""
+        slot = C.c_int32()
+        self._chk(self.L.ksfd_snapshot_begin(self.h, layout, C.byref(slot)))
+        return slot.value
+
+    def snapshot_wait(self, slot):
+        """numpy view (no copy) of the pinned buffer; valid until the second-next snapshot_begin"""
+        ptr = C.POINTER(C.c_double)()
+        self._chk(self.L.ksfd_snapshot_wait(self.h, slot, C.byref(ptr)))
+        return np.ctypeslib.as_array(ptr, shape=(self.nlocal,))
 
     def set_state_random(self, z_coarse, rho0=9000.0):
         """start_values on the device: z_coarse indexed [i,j,k] (x first) on the global coarse grid (ksfdsolver2.py:580-639)"""

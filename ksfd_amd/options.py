@@ -68,6 +68,8 @@ def parse_commandline(argv):
     p.add_argument('--cappotential', choices=['tophat', 'witch'], default='tophat')
     p.add_argument('--save')
     p.add_argument('--check')
+    p.add_argument('--async_save', action='store_true')      # extension: write the series from a background thread
+    p.add_argument('--saveevery', type=int, default=1)       # extension: keep every N-th step in the series
     p.add_argument('--resume')
     p.add_argument('--restart')
     p.add_argument('--series_retries', type=int, default=0)

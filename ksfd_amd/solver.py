@@ -118,7 +118,7 @@ def main(*args):
     ts.setMonitor(ts.printMonitor)
     tseries = None
     if cl.save:
-        tseries = TimeSeries(cl.save, derivs.grid, mode='w')
+        tseries = TimeSeries(cl.save, derivs.grid, mode='w', async_save=cl.async_save, save_every=cl.saveevery)
         tseries.set_dt(float(v['dt']))
         save, closer = ts.makeSaveMonitor(tseries)
         ts.setMonitor(save)

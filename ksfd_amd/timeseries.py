@@ -37,7 +37,13 @@ def _grid_value(grid, a):
 
 
 class TimeSeries:
-    def __init__(self, basename, grid, mode='w', comm=None, backend=None):
+    def __init__(self, basename, grid, mode='w', comm=None, backend=None, async_save=False, save_every=1):
+        """async_save: device states are copied out on a third HIP stream (ksfd_snapshot_begin/_wait) and written by a
+        background thread, so the stepper does not wait for PCIe or the file system; at most two snapshots are in
+        flight and a store blocks when both are.  save_every=N keeps every N-th store (decimation; the reference
+        stores every step, ksfdts.py:466-497)."""
+        self.async_save, self.save_every, self._nstore = bool(async_save), max(1, int(save_every)), 0
+        self._pool, self._outstanding = None, []
         self.grid = grid
         self.rank = getattr(getattr(grid, 'comm', None), 'rank', 0)
         self.size = getattr(getattr(grid, 'comm', None), 'size', 1)
@@ -62,14 +68,36 @@ class TimeSeries:
     def store(self, data, t, k=None):
         """data: Vec-like with .array in PETSc layout, a DeviceVec, or an ndarray in PETSc layout."""
         ks = getattr(data, '_ks', None)
+        if k is None:
+            k = self.lastk + 1
+        self.lastk = k
+        self._nstore += 1
+        if (self._nstore - 1) % self.save_every:
+            return
+        if ks is not None and self.async_save:
+            self._drain(1)                                              # the slot about to be reused must have been written
+            slot = ks.snapshot_begin(HDF5)
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=1)          # one writer: stores stay in order
+            self._outstanding.append(self._pool.submit(self._write_snapshot, ks, slot, int(k), float(t)))
+            return
         if ks is not None:
             Cv = ks.get_state(HDF5).reshape(self.grid.Vlshape)         # device -> (dof,nx,ny[,nz]) C order directly
         else:
             a = np.asarray(getattr(data, 'array', data))
             Cv = np.ascontiguousarray(a.reshape(self.grid.Vlshape, order='F'))
-        if k is None:
-            k = self.lastk + 1
-        self.lastk = k
+        self._commit(k, t, Cv)
+
+    def _write_snapshot(self, ks, slot, k, t):
+        self._commit(k, t, ks.snapshot_wait(slot).reshape(self.grid.Vlshape))
+
+    def _drain(self, keep=0):
+        while len(self._outstanding) > keep:
+            self._outstanding.pop(0).result()                           # re-raises a writer exception here
+
+    def _commit(self, k, t, Cv):
+        self._lastk_written = int(k)
         self.ks.append(int(k))
         self.ts.append(float(t))
         if self.backend == 'h5':
@@ -77,7 +105,7 @@ class TimeSeries:
             self._write_index()
             self.tsFile.flush()
         else:
-            self._data['data%d' % k] = Cv
+            self._data['data%d' % k] = np.array(Cv)                     # own copy: Cv may be a view of a pinned staging buffer
             self._data['t%d' % k] = np.float64(t)
             self._flush_npz()
 
@@ -87,7 +115,7 @@ class TimeSeries:
         f.write('/times', ts)
         f.write('/order', np.argsort(ts))
         f.write('/ks', np.array(self.ks))
-        f.write('/lastk', self.lastk)
+        f.write('/lastk', getattr(self, '_lastk_written', self.lastk))     # async: the main thread may be ahead of the file
         for key, v in self.info.items():
             f.write('/info/' + key, v)
 
@@ -109,6 +137,7 @@ class TimeSeries:
         pass
 
     def flush(self):
+        self._drain()
         if self.backend == 'npz':
             self._flush_npz()
         elif self.tsFile:
@@ -116,6 +145,10 @@ class TimeSeries:
             self.tsFile.flush()
 
     def close(self):
+        self._drain()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
         if self.backend == 'h5':
             if self.tsFile:
                 self._write_index()

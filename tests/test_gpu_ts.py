@@ -159,3 +159,50 @@ def test_time_dependent_parameter_is_resent_each_step():
     for k in range(3):
         u, _, _, _ = ko.Oracle(ps.problem_config(0.01 * k)).rosw_step(u, 0.01, 0.01, 1e-6, solver='lu')
     assert rel_l2(got, u) < 1e-10
+
+
+def test_async_and_decimated_save_equal_the_synchronous_series(tmp_path):
+    """--async_save: snapshots leave on a third stream and a writer thread stores them; the file is identical to the
+    synchronous one.  --saveevery=5 keeps steps 0,5,10,..."""
+    from ksfd_amd import solver
+    from ksfd_amd.timeseries import read_series
+    optfile = '@' + os.path.join(GOLDEN, 'options', 'ks2d_two_ligands.txt')
+    runs = {}
+    for name, extra in (('sync', ()), ('async', ('--async_save',)), ('dec', ('--async_save', '--saveevery=5'))):
+        prefix = str(tmp_path / name / 'run')
+        ts = solver.main('ksfd', optfile, '--save=' + prefix, *extra)
+        runs[name] = read_series(prefix)
+        ts.cleanup()
+    a, b, c = runs['sync'], runs['async'], runs['dec']
+    assert list(a['ks']) == list(b['ks']) == list(range(26))
+    assert np.array_equal(a['times'], b['times'])
+    for k in a['ks']:
+        assert np.array_equal(a['data'][int(k)], b['data'][int(k)]), k
+    assert list(c['ks']) == [0, 5, 10, 15, 20, 25]
+    for k in c['ks']:
+        assert np.array_equal(a['data'][int(k)], c['data'][int(k)])
+
+
+def test_snapshot_slots_hold_their_state_while_the_stepper_moves_on():
+    from ksfd_amd import lib as klib
+    from ksfd_amd.config import ProblemConfig
+    from ksfd_amd.layout import SOA, HDF5
+    cfg = ProblemConfig.standard(2, (64, 48), L=(0.2, 0.15), nlig=1)
+    rng = np.random.default_rng(2)
+    u = 9000 + 90 * rng.standard_normal(cfg.F * cfg.N)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    s0 = k.snapshot_begin(SOA)
+    t, h, st, rc = k.step(0.0, 1e-3)
+    u1 = k.get_state()
+    s1 = k.snapshot_begin(HDF5)
+    t, h, st, rc = k.step(t, h)
+    assert s0 != s1
+    assert np.array_equal(k.snapshot_wait(s0), u)                      # taken before the first step touched the state
+    assert np.array_equal(k.snapshot_wait(s1), _to_hdf5(u1, cfg))       # state after step 1, although step 2 has run since
+    k.close()
+
+
+def _to_hdf5(soa, cfg):
+    F, (nx, ny) = cfg.F, cfg.n[:2]
+    return np.ascontiguousarray(soa.reshape(F, ny, nx).transpose(0, 2, 1)).reshape(-1)     # (dof, x, y) C order
