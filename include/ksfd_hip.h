@@ -197,7 +197,8 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * bit3 set = pipelined GMRES with device-resident Hessenberg/Givens state (off by default);
  * bit4 set = no Krylov recycling across the four stage systems of a step, bit5 set = recycle from every earlier stage
  * (default: from the stages measured to matter: 1 for 2 and 3, 1 and 3 for 4), bits 6-8 = leading Arnoldi vectors kept
- * per stage (1..4, 0 keeps the default 3);
+ * per stage (1..4, 0 keeps the default 3); bit9 set = keep the polynomial preconditioner's temporaries and coefficient
+ * copy in fp64 (default: fp32 storage inside p(A) only; the Krylov vectors, A z_j and the solution are fp64 always);
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

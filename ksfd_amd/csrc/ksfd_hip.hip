@@ -107,6 +107,8 @@ struct ksfd_handle {
     int poly_max_deg = 6;
     double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
+    float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
+    bool poly_fp32 = true;          // Horner temporaries and coefficients of p(A) in fp32 storage (the outer A z_j stays fp64)
 
     // asynchronous snapshots for writers (ksfd_snapshot_begin / _wait): layout transform on the compute stream into a
     // device staging slot, D2H on a third stream into pinned memory while the stepper carries on
@@ -386,8 +388,11 @@ static int op_jcoef(ksfd_handle *h, const double *u)
 {
     const KGeom &G = h->G;
     int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    Scope sc(h, KC_GFIELD, 8.0 * (G.F + 3 + h->P.nlig) * (double)G.plane);
-    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef));
+    if (!h->coef32 && h->poly_fp32 && fused_ok(h) && h->P.nlig <= 4 && G.plane % 2 == 0 && G.inner % 2 == 0 &&
+        hipMalloc((void **)&h->coef32, sizeof(float) * (size_t)(3 + h->P.nlig) * G.plane) != hipSuccess) { h->coef32 = nullptr; h->poly_fp32 = false; }
+    float *c32 = h->poly_fp32 ? h->coef32 : nullptr;
+    Scope sc(h, KC_GFIELD, (8.0 * (G.F + 3 + h->P.nlig) + (c32 ? 4.0 * (3 + h->P.nlig) : 0.0)) * (double)G.plane);
+    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef, c32));
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
 }
@@ -480,6 +485,55 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
+}
+
+// The same strip kernel with mixed storage types (fp32 coefficient copy / Horner temporaries of the polynomial
+// preconditioner).  Same overlap scheme as op_jvp_frozen_halo; a float vector travels through the double-typed transport
+// as half as many doubles (inner and plane are even on this path).
+template <typename TC, typename TV, typename TY, typename TO>
+static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const TC *C, const TV *v, int mode, double shift,
+                          TO *out, const TY *yadd, double alpha, double beta)
+{
+    const KGeom &G = h->G;
+    const double per_pt = (3.0 + h->P.nlig) * sizeof(TC) + G.F * (double)(sizeof(TV) + sizeof(TO)) + ((mode == 2 || mode == 3) ? G.F * (double)sizeof(TY) : 0.0);
+    Scope sc(h, KC_JVP, per_pt * (double)G.nloc * frac);
+    NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, TC, TV, TY, TO>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st,
+                                                                     G, h->P, K, C, (const TV *)v, mode, shift, out, yadd, alpha, beta));
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+template <typename TC, typename TV, typename TY, typename TO>
+static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shift, TO *out, const TY *yadd, double alpha, double beta)
+{
+    const KGeom &G = h->G;
+    KStrips K = make_strips(h, true);
+    if (h->size == 1) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
+    const long long scale = sizeof(double) / sizeof(TV);            // 1 for double, 2 for float
+    const bool ovl = h->overlap && K.nseg >= 3;
+    int rc;
+    if (ovl) {
+        HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
+        KStrips Ki = K;
+        Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = K.nseg - 2;
+        long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
+        Ki.nblocks = (int)((nb + 7) / 8 * 8);
+        if ((rc = jvp2d_launch_t(h, Ki, (double)Ki.nseg / K.nseg, C, v, mode, shift, out, yadd, alpha, beta))) return rc;
+        HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
+    }
+    {
+        Scope sc(h, KC_HALO, 4.0 * 2.0 * sizeof(TV) * G.F * (double)G.inner * 2.0);
+        if (h->tr->exchange(reinterpret_cast<double *>(v), G.F, G.plane / scale, G.inner / scale, G.sloc, G.ng, ovl ? h->st_comm : h->st))
+            return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    }
+    if (!ovl) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
+    HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
+    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
+    KStrips Kb = K;
+    Kb.seg0 = 0; Kb.seg_stride = K.nseg - 1; Kb.nseg = 2;
+    long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
+    Kb.nblocks = (int)((nb + 7) / 8 * 8);
+    return jvp2d_launch_t(h, Kb, 2.0 / K.nseg, C, v, mode, shift, out, yadd, alpha, beta);
 }
 
 // VW = 2 when every plane/offset/length is even (all accesses 16-byte aligned double2)
@@ -610,6 +664,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     double *bufs[] = { h->Zb, h->pvec, h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
     for (double *b : bufs) if (b) hipFree(b);
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
+    if (h->coef32) hipFree(h->coef32);
     if (h->hres) hipHostFree(h->hres);
     if (h->gm_host) hipHostFree(h->gm_host);
     if (h->gm_dev) hipFree(h->gm_dev);
@@ -1447,6 +1502,23 @@ static int poly_apply(ksfd_handle *h, double shift, double *v, double *z)
     int rc;
     const int d = h->poly_deg;
     const double *al = h->poly_alpha;
+    if (h->poly_fp32 && h->coef32 && fused_ok(h)) {
+        // mixed precision: the Horner temporaries and the coefficient planes live in fp32 (half the traffic of every
+        // application but the arithmetic stays fp64); v is read and z written in fp64.  p(A) becomes a slightly
+        // different fixed linear operator, which flexible GMRES does not care about: w_j = A z_j is computed in fp64
+        // from the stored z_j, so the Arnoldi relation and the solution keep full accuracy.
+        const float *C = h->coef32;
+        float *tf[2] = { reinterpret_cast<float *>(h->t1), reinterpret_cast<float *>(h->t2) };
+        const double *nod = nullptr;
+        if (d == 1) return jvp2d_halo_t<float, double, double, double>(h, C, v, 4, shift, z, nod, al[0], al[1] / shift);
+        if ((rc = jvp2d_halo_t<float, double, double, float>(h, C, v, 4, shift, tf[0], nod, al[d - 1], al[d] / shift))) return rc;
+        int cur32 = 0;
+        for (int i = d - 2; i >= 1; i--) {
+            if ((rc = jvp2d_halo_t<float, float, double, float>(h, C, tf[cur32], 3, shift, tf[cur32 ^ 1], (const double *)v, al[i], 1.0 / shift))) return rc;
+            cur32 ^= 1;
+        }
+        return jvp2d_halo_t<float, float, double, double>(h, C, tf[cur32], 3, shift, z, (const double *)v, al[0], 1.0 / shift);
+    }
     double *tmp[2] = { h->t1, h->t2 };
     // t_{d-1} = alpha_{d-1} v + (alpha_d/shift) A v
     double *cur = (d == 1) ? z : tmp[0];
@@ -2066,6 +2138,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->async_mode = (use_fused & 8) ? 1 : 0;
         h->rec_mode = (use_fused & 16) ? 0 : ((use_fused & 32) ? 2 : 1);
         if ((use_fused >> 6) & 7) h->rec_keep = std::min((use_fused >> 6) & 7, 4);
+        h->poly_fp32 = !(use_fused & 512);
     }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;

@@ -373,6 +373,16 @@ __device__ __forceinline__ void ksfd_st2(double *p, double a, double b)
 {
     *reinterpret_cast<double2 *>(p) = make_double2(a, b);
 }
+// fp32 STORAGE (arithmetic stays fp64): used only inside the polynomial preconditioner, see poly_apply
+__device__ __forceinline__ double2 ksfd_ld2(const float *p)
+{
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    return make_double2((double)t.x, (double)t.y);
+}
+__device__ __forceinline__ void ksfd_st2(float *p, double a, double b)
+{
+    *reinterpret_cast<float2 *>(p) = make_float2((float)a, (float)b);
+}
 
 // x-neighbours of a 2-column pair through wave shuffles.  For the pair (a0,a1) at columns (c,c+1):
 // left lane holds (c-2,c-1), right lane (c+2,c+3).
@@ -628,7 +638,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_fused(KGeom G, KPhys P, KS
 // ---------------------------------------------------------------------------------------------
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jcoef(KGeom G, KPhys P, const double *__restrict__ u,
-                                                      double *__restrict__ C)
+                                                      double *__restrict__ C, float *__restrict__ C32 = nullptr)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < G.plane; e += stride) {
@@ -643,6 +653,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jcoef(KGeom G, KPhys P, const do
         C[2 * G.plane + e] = gr;
 #pragma unroll
         for (int l = 0; l < NL; l++) C[(long long)(3 + l) * G.plane + e] = GU[l];
+        if (C32) {                                   // copy for the polynomial preconditioner's Jacobian actions
+            C32[e] = (float)rho;
+            C32[G.plane + e] = (float)g;
+            C32[2 * G.plane + e] = (float)gr;
+#pragma unroll
+            for (int l = 0; l < NL; l++) C32[(long long)(3 + l) * G.plane + e] = (float)GU[l];
+        }
     }
 }
 
@@ -660,10 +677,12 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
     }
 }
 
-template <int NL>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const double *__restrict__ C,
-                                                             const double *__restrict__ v, int mode, double shift,
-                                                             double *__restrict__ out, const double *__restrict__ yadd = nullptr,
+// Storage types: TC coefficient planes, TV input vector, TY the added vector of modes 2/3, TO output (double everywhere
+// except inside the polynomial preconditioner, whose Horner temporaries and coefficient copy are fp32).
+template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const TC *__restrict__ C,
+                                                             const TV *__restrict__ v, int mode, double shift,
+                                                             TO *__restrict__ out, const TY *__restrict__ yadd = nullptr,
                                                              double alpha = 0.0, double beta = 0.0)
 {
     // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x) ;
