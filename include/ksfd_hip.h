@@ -199,6 +199,7 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * (default: from the stages measured to matter: 1 for 2 and 3, 1 and 3 for 4), bits 6-8 = leading Arnoldi vectors kept
  * per stage (1..4, 0 keeps the default 3); bit9 set = keep the polynomial preconditioner's temporaries and coefficient
  * copy in fp64 (default: fp32 storage inside p(A) only; the Krylov vectors, A z_j and the solution are fp64 always);
+ * bit10 set = form the stage vectors with separate passes instead of inside the RHS kernel;
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

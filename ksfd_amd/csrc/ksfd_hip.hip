@@ -108,6 +108,7 @@ struct ksfd_handle {
     double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
     float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
+    bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path)
     bool poly_fp32 = true;          // Horner temporaries and coefficients of p(A) in fp32 storage (the outer A z_j stays fp64)
 
     // asynchronous snapshots for writers (ksfd_snapshot_begin / _wait): layout transform on the compute stream into a
@@ -339,14 +340,15 @@ static KSrc src_of(const ksfd_handle *h, int stage)
 }
 
 // out = f(u) (+sources of `stage`); u must have valid ghosts when size>1
-static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out)
+static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr)
 {
     const KGeom &G = h->G;
     KSrc S = src_of(h, stage);
     if (fused_ok(h)) {
         KStrips K = make_strips(h);
-        Scope sc(h, KC_RHS, vbytes(h, 2));
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out));
+        KComb C = cmb ? *cmb : KComb{};
+        Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out, C));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -1975,8 +1977,19 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const bool use_async = !use_pc && !use_poly && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
                                (h->size == 1 || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
+        const bool fuse_stage = fused_ok(h) && h->P.nlig <= 4 && h->fuse_stage;
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
+            if (fuse_stage) {
+                // stage argument and Zdot term folded into the RHS kernel (no Z vector, no separate passes)
+                KComb cmb = KComb{};
+                for (int j = 0; j < i; j++) {
+                    if (h->At[i][j] != 0.0) { cmb.yin[cmb.nin] = h->Y + (int64_t)j * vs; cmb.ain[cmb.nin++] = h->At[i][j]; }
+                    if (h->Ginv[i][j] != 0.0) { cmb.yout[cmb.nout] = h->Y + (int64_t)j * vs; cmb.aout[cmb.nout++] = -h->Ginv[i][j] / hh; }
+                }
+                if (i > 0 && (rc = halo(h, h->Y + (int64_t)(i - 1) * vs))) break;     // ghosts of the newest stage vector (earlier ones done)
+                if ((rc = op_rhs(h, h->u, i, h->bvec, &cmb))) break;
+            } else {
             if (i > 0) {
                 const double *xs[5]; double a[5]; int nt = 0;
                 xs[nt] = h->u; a[nt++] = 1.0;
@@ -1993,6 +2006,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 xs[nt] = h->bvec; a[nt++] = 1.0;
                 for (int j = 0; j < i; j++) if (h->Ginv[i][j] != 0.0) { xs[nt] = h->Y + (int64_t)j * vs; a[nt++] = -h->Ginv[i][j] / hh; }
                 if (nt > 1 && (rc = op_lincomb(h, nt, xs, a, h->bvec))) break;
+            }
             }
             LinStats ls;
             rc = use_async ? gmres_async(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls)
@@ -2139,6 +2153,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->rec_mode = (use_fused & 16) ? 0 : ((use_fused & 32) ? 2 : 1);
         if ((use_fused >> 6) & 7) h->rec_keep = std::min((use_fused >> 6) & 7, 4);
         h->poly_fp32 = !(use_fused & 512);
+        h->fuse_stage = !(use_fused & 1024);
     }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;

@@ -17,6 +17,14 @@ struct KSrc {
     const double *p[KSFD_MAXL + 1];   // dense nloc-sized source planes (no ghosts) or NULL
 };
 
+// Stage-vector algebra of the Rosenbrock step folded into the RHS kernel: the input is u + sum_j ain[j]*yin[j] (formed on
+// load, before the clamp), the output gets sum_j aout[j]*yout[j] added at the store.  Vectors in the ghosted layout.
+struct KComb {
+    int nin, nout;
+    const double *yin[3], *yout[3];
+    double ain[3], aout[3];
+};
+
 // ---------------------------------------------------------------------------------------------
 // generic family
 // ---------------------------------------------------------------------------------------------
@@ -444,7 +452,7 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
 
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KStrips S, const double *__restrict__ u,
-                                                            KSrc src, double *__restrict__ out)
+                                                            KSrc src, double *__restrict__ out, KComb cmb = KComb{})
 {
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;                       // whole waves only; the kernel has no block barrier
@@ -460,6 +468,16 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
         for (int l = 0; l < NL; l++) {
             double2 q = ksfd_ld2(u + (long long)(l + 1) * G.plane + o);
             nu[l][0] = q.x; nu[l][1] = q.y;
+        }
+        for (int j = 0; j < cmb.nin; j++) {        // wave-uniform: stage argument u + sum a_j Y_j
+            const double a = cmb.ain[j];
+            double2 y = ksfd_ld2(cmb.yin[j] + o);
+            nr[0] += a * y.x; nr[1] += a * y.y;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                double2 q = ksfd_ld2(cmb.yin[j] + (long long)(l + 1) * G.plane + o);
+                nu[l][0] += a * q.x; nu[l][1] += a * q.y;
+            }
         }
     };
     auto push_row = [&]() {                     // shift windows up one row, append the prefetched row
@@ -525,6 +543,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
                 if (src.p[c]) { double2 s = ksfd_ld2(src.p[c] + pi); a += s.x; b += s.y; }
+                for (int j = 0; j < cmb.nout; j++) {
+                    const double2 y = ksfd_ld2(cmb.yout[j] + (long long)c * G.plane + o);
+                    a += cmb.aout[j] * y.x; b += cmb.aout[j] * y.y;
+                }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
             }
         }
