@@ -176,7 +176,7 @@ def main():
                                                                       'TSAdaptBasic rtol=1e-6 atol=0.01 from dt=%g' % args.dt),
                        'grid': [args.n] * args.dim, 'fields': cfg.F, 'ksp_rtol': args.ksp_rtol,
                        'h_mean': float(np.mean(hs)), 'gmres_its_per_step': its / args.steps, 'rejections': rej,
-                       't_end': t, 'parallelism': 'slab%d' % world,
+                       't_end': t, 'parallelism': 'slab%d' % world, 'preconditioner': 'Chebyshev polynomial p(A), fp32 storage of its temporaries/coefficient copy (fp64 arithmetic; Krylov vectors, A z_j, solution fp64)' if not (int(os.environ.get('KSFD_TUNE', '1')) & 512) else 'Chebyshev polynomial p(A), fp64',
                        'transport': type(keep).__name__ if keep is not None else 'none'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,

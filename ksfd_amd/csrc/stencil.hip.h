@@ -751,6 +751,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
     for (long long r = J.r0; r < J.r1; r++) {
         push_row();
         if (r + 1 < J.r1) load_row(J.row(r + 3));
+        // the added vector of modes 2/3 is needed only at the store: issue its loads now, behind the next row's
+        double2 yv[NL + 1];
+        if ((mode == 2 || mode == 3) && J.store) {
+            const long long oy = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) yv[c] = ksfd_ld2(yadd + (long long)c * G.plane + oy);
+        }
         const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
         const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
         const KX xv = ksfd_xnb(vw[2][0], vw[2][1]);
@@ -798,7 +805,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                     const double c0 = c == 0 ? vw[2][0] : zw[c > 0 ? c - 1 : 0][2][0], c1 = c == 0 ? vw[2][1] : zw[c > 0 ? c - 1 : 0][2][1];
                     a = alpha * c0 + beta * a; b = alpha * c1 + beta * b;
                 } else if (mode >= 2) {
-                    const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o);
+                    const double2 yy = yv[c];
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
