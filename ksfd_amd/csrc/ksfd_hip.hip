@@ -267,7 +267,7 @@ static int alloc_d(ksfd_handle *h, double **p, int64_t n)
 
 static bool fused_ok(const ksfd_handle *h)
 {
-    return h->use_fused && h->G.dim == 2 && (h->G.nx % 2 == 0) && h->G.nx >= 4 && h->P.nlig <= 4;
+    return h->use_fused && h->G.dim == 2 && (h->G.nx % 2 == 0) && h->G.nx >= 4 && h->G.sloc >= 4 && h->P.nlig <= 4;
 }
 
 // ---- halo exchange (DMDA globalToLocal stand-in, KSFD/ksfdsym.py:919-920) -----------------------

@@ -11,6 +11,7 @@
 //    x-neighbours come from wave shuffles, the y-neighbours from the window.  Compulsory HBM
 //    traffic only: read F planes, write F planes (+4 halo rows per segment, L2 hits).
 #pragma once
+#include <type_traits>
 #include "pointwise.hip.h"
 
 struct KSrc {
@@ -368,9 +369,9 @@ __device__ __forceinline__ int ksfd_xcd_remap(int b, int nblocks)
 __device__ __forceinline__ long long ksfd_rowoff(const KGeom &G, long long r)
 {
     // r may be -2..sloc+1
-    if (G.wrap_slow) {
-        r %= G.sloc;
+    if (G.wrap_slow) {                   // no 64-bit modulo here: it costs ~100 instructions per row and wave
         if (r < 0) r += G.sloc;
+        else if (r >= G.sloc) r -= G.sloc;
         return r * G.nx;
     }
     return (r + G.ng) * G.nx;
@@ -397,13 +398,30 @@ __device__ __forceinline__ void ksfd_st2(float *p, double a, double b)
 struct KX {
     double l0, l1, r0, r1;
 };
+// Neighbour-lane moves as DPP wavefront shifts (GFX9 dpp_ctrl wave_shr:1 = 0x138, wave_shl:1 = 0x130): a v_mov_dpp per
+// 32-bit half instead of a ds_bpermute through the LDS crossbar.  Same result as __shfl_up/__shfl_down by one lane
+// (lane 0 / lane 63 keep their own value: old == src, bound_ctrl off).
+__device__ __forceinline__ double ksfd_lane_from_left(double a)
+{
+    int lo = __double2loint(a), hi = __double2hiint(a);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ksfd_lane_from_right(double a)
+{
+    int lo = __double2loint(a), hi = __double2hiint(a);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ KX ksfd_xnb(double a0, double a1)
 {
     KX x;
-    x.l0 = __shfl_up(a0, 1, KSFD_WAVE);
-    x.l1 = __shfl_up(a1, 1, KSFD_WAVE);
-    x.r0 = __shfl_down(a0, 1, KSFD_WAVE);
-    x.r1 = __shfl_down(a1, 1, KSFD_WAVE);
+    x.l0 = ksfd_lane_from_left(a0);
+    x.l1 = ksfd_lane_from_left(a1);
+    x.r0 = ksfd_lane_from_right(a0);
+    x.r1 = ksfd_lane_from_right(a1);
     return x;
 }
 // h*d/dx and h^2*d2/dx2 for both points of the pair
@@ -701,7 +719,9 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
 
 // Storage types: TC coefficient planes, TV input vector, TY the added vector of modes 2/3, TO output (double everywhere
 // except inside the polynomial preconditioner, whose Horner temporaries and coefficient copy are fp32).
-template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double>
+// PF = rows in flight ahead of the one being computed.  PF = 2 (fits for NL = 1: 226 VGPRs, still 2 waves/SIMD) was measured
+// and gains nothing: the kernel is co-limited by HBM and fp64/VALU issue (~2000 cycles per row and wave), not by latency.
+template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double, int PF = 1>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const TC *__restrict__ C,
                                                              const TV *__restrict__ v, int mode, double shift,
                                                              TO *__restrict__ out, const TY *__restrict__ yadd = nullptr,
@@ -713,20 +733,24 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;
     double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
-    double nr[2], ng[2], nq[2], nv[2], nc[NL][2], nz[NL][2];
+    double nr[PF][2], ng[PF][2], nq[PF][2], nv[PF][2], nc[PF][NL][2], nz[PF][NL][2];
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, (PF > 1 ? 1 : 0)> B1;
 
-    auto load_row = [&](long long r) {
+    auto load_row = [&](auto Bc, long long r) {
+        constexpr int B = decltype(Bc)::value;
         const long long o = ksfd_rowoff(G, r) + J.c0;
         double2 a = ksfd_ld2(C + o), b = ksfd_ld2(C + G.plane + o), c = ksfd_ld2(C + 2 * G.plane + o), w = ksfd_ld2(v + o);
-        nr[0] = a.x; nr[1] = a.y; ng[0] = b.x; ng[1] = b.y; nq[0] = c.x; nq[1] = c.y; nv[0] = w.x; nv[1] = w.y;
+        nr[B][0] = a.x; nr[B][1] = a.y; ng[B][0] = b.x; ng[B][1] = b.y; nq[B][0] = c.x; nq[B][1] = c.y; nv[B][0] = w.x; nv[B][1] = w.y;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             double2 q = ksfd_ld2(C + (long long)(3 + l) * G.plane + o);
             double2 z = ksfd_ld2(v + (long long)(l + 1) * G.plane + o);
-            nc[l][0] = q.x; nc[l][1] = q.y; nz[l][0] = z.x; nz[l][1] = z.y;
+            nc[B][l][0] = q.x; nc[B][l][1] = q.y; nz[B][l][0] = z.x; nz[B][l][1] = z.y;
         }
     };
-    auto push_row = [&]() {
+    auto push_row = [&](auto Bc) {
+        constexpr int B = decltype(Bc)::value;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
 #pragma unroll
@@ -739,18 +763,20 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            double d = nq[e] * nv[e];
+            double d = nq[B][e] * nv[B][e];
 #pragma unroll
-            for (int l = 0; l < NL; l++) { d += nc[l][e] * nz[l][e]; zw[l][4][e] = nz[l][e]; }
-            rw[4][e] = nr[e]; gw[4][e] = ng[e]; vw[4][e] = nv[e]; ew[4][e] = d;
+            for (int l = 0; l < NL; l++) { d += nc[B][l][e] * nz[B][l][e]; zw[l][4][e] = nz[B][l][e]; }
+            rw[4][e] = nr[B][e]; gw[4][e] = ng[B][e]; vw[4][e] = nv[B][e]; ew[4][e] = d;
         }
     };
 
-    for (int q = -2; q <= 1; q++) { load_row(J.row(J.r0 + q)); push_row(); }
-    load_row(J.row(J.r0 + 2));
-    for (long long r = J.r0; r < J.r1; r++) {
-        push_row();
-        if (r + 1 < J.r1) load_row(J.row(r + 3));
+    for (int q = -2; q <= 1; q++) { load_row(B0(), J.row(J.r0 + q)); push_row(B0()); }
+    load_row(B0(), J.row(J.r0 + 2));
+    if (PF > 1 && J.r0 + 1 < J.r1) load_row(B1(), J.row(J.r0 + 3));
+    // one row: window <- pending buffer (holds row r+2), refill that buffer with row r+2+PF, compute and store row r
+    auto do_row = [&](auto Bc, long long r) {
+        push_row(Bc);
+        if (r + PF < J.r1) load_row(Bc, J.row(r + 2 + PF));
         // the added vector of modes 2/3 is needed only at the store: issue its loads now, behind the next row's
         double2 yv[NL + 1];
         if ((mode == 2 || mode == 3) && J.store) {
@@ -810,6 +836,14 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
             }
+        }
+    };
+    if (PF == 1) {
+        for (long long r = J.r0; r < J.r1; r++) do_row(B0(), r);
+    } else {
+        for (long long r = J.r0; r < J.r1; r += 2) {
+            do_row(B0(), r);
+            if (r + 1 < J.r1) do_row(B1(), r + 1);
         }
     }
 }
