@@ -1,0 +1,91 @@
+"""GPU, BASELINE.json sizes: parity through size-independent properties (the oracle cannot run at these sizes in seconds).
+
+  * periodic translation invariance  f(shift u) = shift f(u), J(shift u) shift v = shift (J(u) v)
+  * linearity of the Jacobian action and its consistency with a centred difference of the RHS
+  * known answer on a uniform state
+  * periodic replication: a 512^2 state tiled 8x8 is a 4096^2 state with the same spacing; one implicit step of the big
+    problem must be the tiling of the small problem's step (which the small-size tests tie to the oracle / golden vectors)
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from ksfd_amd import lib as klib
+from ksfd_amd.config import ProblemConfig
+
+pytestmark = pytest.mark.gpu
+SP = 4.0 / 1536                      # options84 grid spacing
+
+
+def _cfg(shape, nlig):
+    return ProblemConfig.standard(len(shape), shape, L=tuple(n * SP for n in shape), nlig=nlig)
+
+
+def _state(cfg, seed):
+    rng = np.random.default_rng(seed)
+    rho = 9000.0 + 90.0 * rng.standard_normal(cfg.N)
+    parts = [rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1.0 + 0.01 * rng.standard_normal(cfg.N)) for l in range(cfg.nlig)]
+    return np.concatenate(parts)
+
+
+def _roll(x, cfg, shifts):
+    F = x.size // cfg.N
+    a = x.reshape((F,) + tuple(reversed(cfg.n[:cfg.dim])))                       # (F, [nz,] ny, nx)
+    for ax, s in enumerate(shifts):
+        a = np.roll(a, s, axis=a.ndim - 1 - ax)
+    return a.reshape(-1)
+
+
+@pytest.mark.parametrize('shape,nlig,shifts', [((4096, 4096), 1, (130, 1717)), ((8192, 8192), 2, (4097, 33)), ((256, 256, 256), 1, (3, 129, 70))])
+def test_translation_invariance_and_linearity_at_baseline_sizes(shape, nlig, shifts):
+    cfg = _cfg(shape, nlig)
+    u = _state(cfg, 1)
+    k = klib.KSFDHip(cfg)
+    f = k.rhs(u)
+    fs = k.rhs(_roll(u, cfg, shifts))
+    assert rel_l2(fs, _roll(f, cfg, shifts)) < 1e-13
+    # uniform state: every difference vanishes -> f_rho = 0, f_U = -gamma U + s rho
+    c = np.concatenate([np.full(cfg.N, 9000.0)] + [np.full(cfg.N, 8000.0 + 100 * l) for l in range(nlig)])
+    fc = k.rhs(c)
+    assert np.abs(fc[:cfg.N]).max() < 1e-9 * 9000.0 * cfg.s2 / SP ** 2
+    for l in range(nlig):
+        want = -cfg.lig_gamma[l] * (8000.0 + 100 * l) + cfg.lig_s[l] * 9000.0
+        assert np.allclose(fc[(l + 1) * cfg.N:(l + 2) * cfg.N], want, rtol=1e-9, atol=0)
+    if cfg.N > 5e7:                                           # 8192^2 x 3 fields: keep the host footprint bounded
+        k.close()
+        return
+    rng = np.random.default_rng(2)
+    v1, v2 = rng.standard_normal(u.size), rng.standard_normal(u.size)
+    k.set_state(u)
+    j1, j2 = k.jvp(v1), k.jvp(v2)
+    assert rel_l2(k.jvp(0.3 * v1 - 1.7 * v2), 0.3 * j1 - 1.7 * j2) < 1e-12
+    k.set_state(_roll(u, cfg, shifts))
+    assert rel_l2(k.jvp(_roll(v1, cfg, shifts)), _roll(j1, cfg, shifts)) < 1e-13
+    # J v against a centred difference of the RHS kernel (two different kernels, same operator)
+    eps = 1e-3
+    fd = (k.rhs(_roll(u, cfg, shifts) + eps * v2) - k.rhs(_roll(u, cfg, shifts) - eps * v2)) / (2 * eps)
+    assert rel_l2(fd, k.jvp(v2)) < 1e-6
+    k.close()
+
+
+def test_step_of_a_tiled_state_is_the_tiled_step():
+    """4096^2 implicit step == 8x8 tiling of the 512^2 step (same spacing, same physics)"""
+    small, big = _cfg((512, 512), 1), _cfg((4096, 4096), 1)
+    us = _state(small, 3)
+    tile = lambda x: np.tile(x.reshape(2, 512, 512), (1, 8, 8)).reshape(-1)
+    opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
+    ks = klib.KSFDHip(small)
+    ks.set_state(us)
+    t, h, st_s, rc = ks.step(0.0, 0.01, opts)
+    want = tile(ks.get_state())
+    wrms_small = st_s.wrms
+    ks.close()
+    kb = klib.KSFDHip(big)
+    kb.set_state(tile(us))
+    t, h, st_b, rc = kb.step(0.0, 0.01, opts)
+    got = kb.get_state()
+    kb.close()
+    assert rel_l2(got, want) < 1e-10
+    assert abs(st_b.wrms - wrms_small) <= 1e-6 * wrms_small              # the WRMS norm is a mean: tiling leaves it alone
+    # the step did something: rho moved by far more than the agreement asked for above
+    assert rel_l2(got[:big.N], tile(us)[:big.N]) > 1e-6
