@@ -1,0 +1,84 @@
+"""GPU: seeded random sweep of problem definitions (dimension, extents incl. odd ones, 1-5 ligands in 1-3 groups, both cap
+potentials, densities from dilute to above rhomax, anisotropic boxes) -- HIP operators and one implicit step against the oracle.
+Deterministic: every case derives from its index."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from ksfd_amd import lib as klib
+from ksfd_amd.config import ProblemConfig
+from oracle import ko
+
+pytestmark = pytest.mark.gpu
+
+
+def random_problem(i, for_step=False):
+    rng = np.random.default_rng(1000 + i)
+    dim = int(rng.choice([1, 2, 2, 2, 3]))
+    if dim == 1:
+        shape = (int(rng.integers(8, 200)),)
+    elif dim == 2:
+        shape = (int(rng.integers(4, 150 if not for_step else 26)), int(rng.integers(4, 80 if not for_step else 22)))
+        if rng.random() < 0.6:
+            shape = (max(6, shape[0] // 2 * 2), shape[1])                    # even nx: strip kernels; odd: generic path
+    else:
+        shape = tuple(int(x) for x in rng.integers(4, 22 if not for_step else 9, size=3))
+    shape = tuple(max(5, s) for s in shape)                     # the width-2 periodic star needs >= 5 points per axis
+    nlig = int(rng.integers(1, 6 if not for_step else 4))
+    ngroups = int(rng.integers(1, min(nlig, 3) + 1))
+    group = np.concatenate([np.arange(ngroups), rng.integers(0, ngroups, size=nlig - ngroups)]).astype(np.int32)
+    rng.shuffle(group)
+    cfg = ProblemConfig(dim=dim, n=shape, L=tuple(float(x) for x in rng.uniform(0.05, 1.5, size=dim)),
+                        lig_group=group, lig_w=rng.uniform(0.3, 2.0, size=nlig),
+                        lig_s=10 ** rng.uniform(-3, -1.5, size=nlig), lig_gamma=10 ** rng.uniform(-3, -1.5, size=nlig),
+                        lig_D=10 ** rng.uniform(-6.5, -4.5, size=nlig),
+                        grp_alpha=rng.uniform(500, 3000, size=ngroups),
+                        grp_beta=rng.choice([-1, 1], size=ngroups) * rng.uniform(2e-4, 8e-4, size=ngroups),
+                        cap_kind=int(rng.integers(0, 2)))
+    N = cfg.N
+    level = float(rng.choice([300.0, 9000.0, 24000.0, 29500.0]))        # dilute ... above rhomax (cap potential active)
+    rho = level * (1.0 + 0.1 * rng.standard_normal(N))
+    parts = [rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1.0 + 0.05 * rng.standard_normal(N)) for l in range(nlig)]
+    u = np.concatenate(parts)
+    if not for_step and rng.random() < 0.3:                             # a few values below the floors / NaN (groom on load)
+        idx = rng.choice(u.size, size=max(1, u.size // 50), replace=False)
+        u[idx[::2]] = -3.0
+        u[idx[1::2]] = np.nan
+    return cfg, u, rng
+
+
+@pytest.mark.parametrize('i', range(100))
+def test_random_problem_operators_vs_oracle(i):
+    cfg, u, rng = random_problem(i)
+    v = rng.standard_normal(u.size)
+    o = ko.Oracle(cfg)
+    k = klib.KSFDHip(cfg)
+    assert rel_l2(k.rhs(u), o.rhs(u)) < 1e-12
+    assert rel_l2(k.jvp(v, u), o.jvp(u, v)) < 1e-12
+    k.set_state(u)
+    assert rel_l2(k.jvp(v), o.jvp(u, v)) < 1e-12                         # frozen-coefficient path of the stepper
+    vmax_o, _ = o.cfl(u)
+    assert np.allclose(k.velocity_max()[:cfg.dim], vmax_o[:cfg.dim], rtol=1e-10, atol=1e-300)
+    k.close()
+
+
+@pytest.mark.parametrize('i', range(40))
+def test_random_problem_step_vs_oracle(i):
+    """one fixed step, every preconditioning regime the stiffness estimate selects for that case"""
+    cfg, u, rng = random_problem(100 + i, for_step=True)
+    h = float(10 ** rng.uniform(-3, 0.5))
+    # Keep shift = 1/(gamma h) above twice the growth rate of the chemotactic instability of this state: beyond that the
+    # stage matrix shift*I - J is indefinite and nearly singular (the LU of the reference still "solves" it, restarted
+    # GMRES stagnates; in an adaptive run the step controller rejects such steps long before).
+    import scipy.sparse as sp
+    rp, col, val = ko.Oracle(cfg).jacobian_csr(u)
+    growth = max(0.0, float(np.linalg.eigvals(sp.csr_matrix((val, col, rp)).toarray()).real.max()))
+    if growth > 0.0:
+        h = min(h, 0.5 / (0.43586652150845900 * growth))
+    un, err, wr, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='lu')          # dense LU: sizes above keep it to seconds
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-12, ksp_max_it=20000))
+    assert rel_l2(k.get_state(), un) < 1e-9, (cfg.n, cfg.nlig, h, st.linear_its)
+    assert abs(st.wrms - wr) <= 1e-5 * wr + 1e-12
+    k.close()
