@@ -200,6 +200,8 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * per stage (1..4, 0 keeps the default 3); bit9 set = keep the polynomial preconditioner's temporaries and coefficient
  * copy in fp64 (default: fp32 storage inside p(A) only; the Krylov vectors, A z_j and the solution are fp64 always);
  * bit10 set = form the stage vectors with separate passes instead of inside the RHS kernel;
+ * bit11 set = fetch reduction results with a stream synchronisation + copy instead of spinning on a flag the
+ * reduction kernel raises in mapped host memory;
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

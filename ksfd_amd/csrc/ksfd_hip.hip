@@ -71,6 +71,11 @@ struct ksfd_handle {
     double *part = nullptr;                 // block partials
     double *dres = nullptr;                 // reduced results (device)
     double *hres = nullptr;                 // pinned host mirror
+    // zero-copy hand-over of reduction results: the kernel stores into hres through its device alias and raises pub_flag
+    double *hres_dev = nullptr;
+    unsigned long long *pub_flag = nullptr, *pub_flag_dev = nullptr, pub_seq = 0;
+    unsigned int *pub_count = nullptr;
+    bool zero_copy = true;
     int restart_alloc = 0;
     int nblk_vec = 0;                       // grid.x of the BLAS-1 kernels
     bool have_err = false;
@@ -282,16 +287,43 @@ static int halo(ksfd_handle *h, double *vec)
 
 // ---- reductions to the host ------------------------------------------------------------------
 // part holds `rows` rows of `nblk` partials; result lands in h->hres[0..rows)
+// host side of the zero-copy hand-over: spin until the kernel has raised the flag (with a look at the stream now and then,
+// so that a faulted launch turns into an error instead of a hang)
+static int spin_for(ksfd_handle *h, unsigned long long seq)
+{
+    for (unsigned long long spins = 1;; spins++) {
+        if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == seq) return KSFD_OK;
+        if ((spins & 0xffff) == 0) {
+            hipError_t e = hipStreamQuery(h->st);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == seq) return KSFD_OK;
+                return fail(h, KSFD_EHIP, "reduction finished without publishing its result");
+            }
+            if (e != hipErrorNotReady) return fail(h, KSFD_EHIP, "stream error while waiting for a reduction: %s", hipGetErrorString(e));
+        }
+    }
+}
+
 static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
 {
+    const bool zc = h->zero_copy && !h->capturing && rows <= 128;
+    const bool zc_here = zc && h->size == 1;
+    const unsigned long long seq = zc ? ++h->pub_seq : 0;
     {
         Scope sc(h, KC_REDUCE, 8.0 * rows * (double)nblk);
-        hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres);
+        if (zc_here) hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres, h->hres_dev, h->pub_count, h->pub_flag_dev, seq);
+        else hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres);
     }
+    if (zc_here) { HIPCHK(h, hipGetLastError()); return spin_for(h, seq); }
     if (h->size > 1) {
         int rc = h->tr->allreduce(h->dres, rows, op, h->st);
         if (rc) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
         if (h->tr->result_on_host()) { memcpy(h->hres, h->tr->host_result(), sizeof(double) * rows); return KSFD_OK; }
+        if (zc) {
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, h->st, (const double *)h->dres, rows, h->hres_dev, h->pub_flag_dev, seq);
+            HIPCHK(h, hipGetLastError());
+            return spin_for(h, seq);
+        }
     }
     HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, sizeof(double) * rows, hipMemcpyDeviceToHost, h->st));
     HIPCHK(h, hipStreamSynchronize(h->st));
@@ -668,6 +700,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
     if (h->coef32) hipFree(h->coef32);
     if (h->hres) hipHostFree(h->hres);
+    if (h->pub_count) hipFree(h->pub_count);
     if (h->gm_host) hipHostFree(h->gm_host);
     if (h->gm_dev) hipFree(h->gm_dev);
     for (auto e : h->gm_ev) if (e) hipEventDestroy(e);
@@ -753,7 +786,12 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
     hipMemsetAsync(h->Y, 0, sizeof(double) * (size_t)(4 * h->vlen), h->st);
     hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)((h->restart_alloc + 1) * h->vlen), h->st);
-    if (hipHostMalloc((void **)&h->hres, sizeof(double) * 128, hipHostMallocDefault) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
+    if (hipHostMalloc((void **)&h->hres, sizeof(double) * 128 + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");
+    h->pub_flag = reinterpret_cast<unsigned long long *>(h->hres + 128);
+    *h->pub_flag = 0;
+    if (hipHostGetDevicePointer((void **)&h->hres_dev, h->hres, 0) != hipSuccess || hipMalloc((void **)&h->pub_count, sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(h->pub_count, 0, sizeof(unsigned int)) != hipSuccess) { h->zero_copy = false; h->hres_dev = nullptr; }
+    else h->pub_flag_dev = reinterpret_cast<unsigned long long *>(h->hres_dev + 128);
     {
         const int m = h->restart_alloc;
         const size_t ndev = (size_t)(m + 1) * (m + 1) + (size_t)(m + 1) * m + 2 * m + (m + 1) + KSFD_MAXDOT + 1 + 2 * (m + 1);
@@ -2154,6 +2192,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         if ((use_fused >> 6) & 7) h->rec_keep = std::min((use_fused >> 6) & 7, 4);
         h->poly_fp32 = !(use_fused & 512);
         h->fuse_stage = !(use_fused & 1024);
+        h->zero_copy = !(use_fused & 2048) && h->hres_dev;
     }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;

@@ -216,8 +216,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_multidot_gram(KVec g, const doub
 }
 
 // out[r] = reduce_b part[r*nblk + b]  (op 0 sum, 1 max); one block per row.
+// pub != NULL: the results are also stored straight into host memory (mapped, coherent) and the block that finishes last
+// raises *flag to seq, so the host can spin on the flag instead of paying a stream synchronisation + D2H copy
+// (~20-30 us per reduction, 30 reductions per step: all of it GPU idle time).
 __global__ void __launch_bounds__(KSFD_BLOCK) k_reduce_rows(const double *__restrict__ part, int nblk, int op,
-                                                            double *__restrict__ out)
+                                                            double *__restrict__ out, double *pub = nullptr,
+                                                            unsigned int *count = nullptr, unsigned long long *flag = nullptr,
+                                                            unsigned long long seq = 0)
 {
     __shared__ double red[KSFD_BLOCK / KSFD_WAVE];
     const double *row = part + (long long)blockIdx.x * nblk;
@@ -230,7 +235,25 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_reduce_rows(const double *__rest
         double t = red[0];
         for (int q = 1; q < KSFD_BLOCK / KSFD_WAVE; q++) t = op ? fmax(t, red[q]) : t + red[q];
         out[blockIdx.x] = t;
+        if (pub) {
+            __hip_atomic_store(pub + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            if (atomicAdd(count, 1u) == gridDim.x - 1) {              // every row's store is ordered before its increment
+                *count = 0;
+                __threadfence_system();
+                __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
+}
+
+// results already reduced across ranks on the device (RCCL): hand them to the spinning host the same way
+__global__ void k_publish(const double *__restrict__ res, int n, double *pub, unsigned long long *flag, unsigned long long seq)
+{
+    if (threadIdx.x < n) __hip_atomic_store(pub + threadIdx.x, res[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Gram-Schmidt update fused with the normalisation:  w = (w - sum_{i<k} h[i] V_i) * scale
