@@ -1,0 +1,472 @@
+// libksfd_hip.so -- Chebyshev polynomial preconditioner, flexible/recycled GMRES(m), pipelined GMRES
+// (part of the single translation unit ksfd_hip.hip; included from there in this order:
+//  handle.hip.h, ops.hip.h, mg_host.hip.h, krylov.hip.h)
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// Polynomial preconditioner.  In the non-stiff regime (h*gamma*lambda_max(J) of order 1..10, the regime of the
+// headline benchmark) plain GMRES needs ~7 iterations per stage and spends most of its time in Gram-Schmidt, whose
+// traffic grows with the square of the iteration count.  z = p(A) v with p the degree-d Chebyshev approximation of
+// 1/lambda on [a, b] (spectrum of A/shift: a ~ 1, b = 1 + lambda_max(-J)/shift) costs d Jacobian actions with a fused
+// Horner epilogue (out = alpha*v + beta*A t, no extra pass) and cuts the outer iterations to 2-3: same number of
+// Jacobian actions, a fraction of the Gram-Schmidt passes.  Used through flexible GMRES (Z basis kept), so the
+// solution update needs no extra preconditioner application.
+// ------------------------------------------------------------------------------------------------
+static int est_lambda_max(ksfd_handle *h, double shift, int nits)
+{
+    int rc;
+    if (!h->pvec) {
+        if (alloc_d(h, &h->pvec, h->vlen)) return KSFD_ENOMEM;
+        int nb = (int)std::min<long long>((h->vlen + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)h->vlen, h->pvec);
+        if ((rc = op_multidot(h, h->pvec, h->pvec, 0))) return rc;
+        const double n0 = sqrt(h->hres[0]);
+        const double *xs[1] = { h->pvec }; double a[1] = { 1.0 / n0 };
+        if ((rc = op_lincomb(h, 1, xs, a, h->pvec))) return rc;
+    }
+    double lamA = 0.0;
+    for (int it = 0; it < nits; it++) {
+        if ((rc = op_jvp_frozen_halo(h, h->pvec, 1, shift, h->t3))) return rc;
+        if ((rc = op_multidot(h, h->t3, h->t3, 0))) return rc;
+        lamA = sqrt(h->hres[0]);
+        if (!(lamA > 0.0) || lamA != lamA) return fail(h, KSFD_ENAN, "power iteration on the Jacobian broke down");
+        const double *xs[1] = { h->t3 }; double a[1] = { 1.0 / lamA };
+        if ((rc = op_lincomb(h, 1, xs, a, h->pvec))) return rc;
+    }
+    const double est = lamA - shift;
+    h->lamJ = est > 0.0 ? est : 0.0;
+    return KSFD_OK;
+}
+
+// coefficients of p for this shift; degree 0 = "do not precondition"
+static void poly_setup(ksfd_handle *h, double shift)
+{
+    const double a = 0.97, b = 1.0 + 1.15 * h->lamJ / shift;      // spectrum of A/shift (power iteration converges from below: +15 %)
+    h->poly_shift = shift;
+    h->poly_deg = 0;
+    const double kappa = b / a;
+    if (kappa < 1.3) return;                                       // GMRES alone needs <= 3 iterations
+    const double rc_ = (sqrt(kappa) - 1.0) / (sqrt(kappa) + 1.0);
+    int d = (int)ceil(log(h->poly_target) / log(rc_)) - 1;         // residual polynomial of degree d+1: ~2 rc^(d+1) <= 2*target
+    d = std::min(std::max(d, 1), std::max(h->poly_max_deg, 1));
+    // r(l) = T_{d+1}(mu(l)) / T_{d+1}(mu(0)), mu(l) = m0 + m1 l;  p(l) = (1 - r(l)) / l
+    const int n = d + 1;
+    double m0 = (b + a) / (b - a), m1 = -2.0 / (b - a);
+    double Tp[10] = { 1.0 }, Tc[10] = { m0, m1 }, Tn[10];
+    int degc = 1;
+    for (int k = 1; k < n; k++) {
+        for (int i = 0; i < 10; i++) Tn[i] = 0.0;
+        for (int i = 0; i <= degc; i++) { Tn[i] += 2.0 * m0 * Tc[i]; Tn[i + 1] += 2.0 * m1 * Tc[i]; }
+        for (int i = 0; i <= degc - 1; i++) Tn[i] -= Tp[i];
+        for (int i = 0; i < 10; i++) { Tp[i] = Tc[i]; Tc[i] = Tn[i]; }
+        degc++;
+    }
+    const double t0 = Tc[0];                                       // T_n(mu(0))
+    for (int i = 0; i <= d; i++) h->poly_alpha[i] = -(Tc[i + 1] / t0) / shift;   // p_i = -r_{i+1}; the 1/shift turns p(A/shift) into ~A^-1
+    h->poly_deg = d;
+}
+
+// z = sum_i alpha_i (A/shift)^i v  by Horner, one fused Jacobian action per degree
+static int poly_apply(ksfd_handle *h, double shift, double *v, double *z)
+{
+    int rc;
+    const int d = h->poly_deg;
+    const double *al = h->poly_alpha;
+    if (h->poly_fp32 && h->coef32 && fused_ok(h)) {
+        // mixed precision: the Horner temporaries and the coefficient planes live in fp32 (half the traffic of every
+        // application but the arithmetic stays fp64); v is read and z written in fp64.  p(A) becomes a slightly
+        // different fixed linear operator, which flexible GMRES does not care about: w_j = A z_j is computed in fp64
+        // from the stored z_j, so the Arnoldi relation and the solution keep full accuracy.
+        const float *C = h->coef32;
+        float *tf[2] = { reinterpret_cast<float *>(h->t1), reinterpret_cast<float *>(h->t2) };
+        const double *nod = nullptr;
+        if (d == 1) return jvp2d_halo_t<float, double, double, double>(h, C, v, 4, shift, z, nod, al[0], al[1] / shift);
+        if ((rc = jvp2d_halo_t<float, double, double, float>(h, C, v, 4, shift, tf[0], nod, al[d - 1], al[d] / shift))) return rc;
+        int cur32 = 0;
+        for (int i = d - 2; i >= 1; i--) {
+            if ((rc = jvp2d_halo_t<float, float, double, float>(h, C, tf[cur32], 3, shift, tf[cur32 ^ 1], (const double *)v, al[i], 1.0 / shift))) return rc;
+            cur32 ^= 1;
+        }
+        return jvp2d_halo_t<float, float, double, double>(h, C, tf[cur32], 3, shift, z, (const double *)v, al[0], 1.0 / shift);
+    }
+    double *tmp[2] = { h->t1, h->t2 };
+    // t_{d-1} = alpha_{d-1} v + (alpha_d/shift) A v
+    double *cur = (d == 1) ? z : tmp[0];
+    if ((rc = op_jvp_frozen_halo(h, v, 4, shift, cur, nullptr, al[d - 1], al[d] / shift))) return rc;
+    int flip = 1;
+    for (int i = d - 2; i >= 0; i--) {
+        double *nxt = (i == 0) ? z : tmp[flip];
+        if ((rc = op_jvp_frozen_halo(h, cur, 3, shift, nxt, v, al[i], 1.0 / shift))) return rc;
+        cur = nxt;
+        flip ^= 1;
+    }
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// matrix-free GMRES(m) for (shift I - J(u)) x = b, x0 = 0  -- replaces -ksp_type preonly -pc_type lu
+// (options84:58-60).  Classical Gram-Schmidt applied twice (CGS2), one fused multi-dot + one fused
+// update kernel per pass; the new vector's norm comes from the second pass by Pythagoras.
+// ------------------------------------------------------------------------------------------------
+struct LinStats { int its; double rel; };
+
+static void rec_reset(ksfd_handle *h)
+{
+    for (auto &r : h->rec) r.valid = false;
+    h->rec_vtop = h->rec_ztop = 0;
+}
+
+// Least squares min ||g - H y|| for a small upper-Hessenberg H ((k+1) x k, column-major, ld = k+1); also returns H y.
+static void hess_lsq(const double *H, int k, const double *g, double *y, double *Hy)
+{
+    double R[20], q[5];
+    const int ld = k + 1;
+    for (int i = 0; i < ld * k; i++) R[i] = H[i];
+    for (int i = 0; i <= k; i++) q[i] = g[i];
+    for (int j = 0; j < k; j++) {
+        const double a = R[j * ld + j], b = R[j * ld + j + 1], den = hypot(a, b);
+        const double c = den > 0.0 ? a / den : 1.0, sn = den > 0.0 ? b / den : 0.0;
+        for (int l = j; l < k; l++) {
+            const double t = c * R[l * ld + j] + sn * R[l * ld + j + 1];
+            R[l * ld + j + 1] = -sn * R[l * ld + j] + c * R[l * ld + j + 1];
+            R[l * ld + j] = t;
+        }
+        const double t = c * q[j] + sn * q[j + 1];
+        q[j + 1] = -sn * q[j] + c * q[j + 1];
+        q[j] = t;
+    }
+    for (int i = k - 1; i >= 0; i--) {
+        double t = q[i];
+        for (int l = i + 1; l < k; l++) t -= R[l * ld + i] * y[l];
+        y[i] = R[i * ld + i] != 0.0 ? t / R[i * ld + i] : 0.0;
+    }
+    for (int i = 0; i <= k; i++) {
+        double t = 0.0;
+        for (int l = 0; l < k; l++) t += H[l * ld + i] * y[l];
+        Hy[i] = t;
+    }
+}
+
+// stage >= 0: Krylov recycling.  The four stage systems of a step share the matrix, and their right-hand sides are
+// nearly linear images of one another (b_i = f(u + sum a_ij Y_j) - sum c_ij Y_j/h with f almost linear over a step), so
+// the leading Arnoldi vectors of an earlier stage (A Z_s = V_s H_s, kept in place at the front of V / Zb) already span
+// most of the new solution: x0 = Z_s y with y = argmin ||V_s^T r - H_s y||, r <- r - V_s H_s y, one space after the
+// other, costs ~5 vector passes per kept vector and removes 1-2 of the 3-4 outer iterations of stages 2-4 (each
+// (d+1) Jacobian actions + Gram-Schmidt).  The iteration then continues on the true residual with the same stopping
+// test, so the result is the same to the solver tolerance.  stage < 0: plain solve from x0 = 0.
+static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
+                 const ksfd_step_opts *o, LinStats *ls, int pcmode, int stage = -1)
+{
+    const bool use_pc = pcmode == 1;       // multigrid, right preconditioning
+    const bool use_poly = pcmode == 2;     // Chebyshev polynomial, flexible GMRES (z_j kept in Zb)
+    // use_pc: right preconditioning with one multigrid V cycle, w = A (M^-1 v_j), x = M^-1 (V y)
+    auto apply_A = [&](const double *vin, double *wout) -> int {
+        return h->use_frozen ? op_jvp_frozen(h, vin, 1, shift, wout) : op_jvp(h, ustate, vin, 1, shift, wout);
+    };
+    const int m_opt = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
+    const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
+    const int64_t vs = h->vlen;
+    bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen;
+    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 10) { if (stage != 0) rec_on = false; rec_reset(h); }
+    const int vb = rec_on ? h->rec_vtop : 0, zb = rec_on ? h->rec_ztop : 0;
+    const int m = std::min(m_opt, h->restart_alloc - vb);
+    double *V = h->V + (int64_t)vb * vs;
+    double *Zq = use_poly ? h->Zb + (int64_t)zb * vs : nullptr;
+    int rc;
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), Hraw((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2), Gm((size_t)(m + 1) * (m + 1), 0.0);
+    if ((rc = op_multidot(h, b, V, 0))) return rc;
+    const double bn = sqrt(h->hres[0]);
+    ls->its = 0; ls->rel = 0.0;
+    if (!(bn > 0.0)) {
+        if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
+        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
+        return KSFD_OK;
+    }
+    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
+    double beta = bn, rn = bn;
+    int total = 0;
+    bool first = true;          // the residual of the current x is at hand (rsrc, norm beta): no A x needed
+    bool x_set = false;         // x holds an iterate (else it is taken as 0 and overwritten)
+    bool restarted = false;
+    const double *rsrc = b;
+    if (rec_on && stage > 0) {
+        static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
+        for (int q = 0; q < stage; q++) {
+            bool use = h->rec_mode == 2;
+            for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
+            const ksfd_handle::RecSpace &S = h->rec[q];
+            if (!use || !S.valid || S.pc != pcmode) continue;
+            const double *Vs = h->V + (int64_t)S.vb * vs;
+            const double *Zs = use_poly ? h->Zb + (int64_t)S.zb * vs : Vs;
+            double gq[5], yq[4], Hy[5], neg[5];
+            if ((rc = op_multidot(h, rsrc, Vs, S.k + 1))) return rc;
+            for (int i = 0; i <= S.k; i++) gq[i] = h->hres[i];
+            hess_lsq(S.H, S.k, gq, yq, Hy);
+            if (use_pc) {
+                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
+                if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
+                else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
+            } else if ((rc = op_basis_axpy(h, x, Zs, S.k, yq, x_set ? 1.0 : 0.0))) return rc;
+            x_set = true;
+            for (int i = 0; i <= S.k; i++) neg[i] = -Hy[i];
+            if (rsrc == b) {
+                const double *xs[6] = { b }; double a[6] = { 1.0 };
+                for (int i = 0; i <= S.k; i++) { xs[i + 1] = Vs + (int64_t)i * vs; a[i + 1] = neg[i]; }
+                if ((rc = op_lincomb(h, S.k + 2, xs, a, h->t3))) return rc;
+                rsrc = h->t3;
+            } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0))) return rc;
+        }
+        if (x_set) {
+            if ((rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
+            beta = rn = sqrt(h->hres[0]);
+            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: projected residual is not finite");
+        }
+    }
+    while (true) {
+        if (first && beta <= tol) break;                       // the recycled spaces already hold the solution
+        // V0 = r / beta
+        if (first) { const double *xs[1] = { rsrc }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
+        else {
+            if ((rc = halo(h, x)) || (rc = apply_A(x, V))) return rc;     // V0 = A x
+            const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
+            if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;                                  // r = b - A x
+            if ((rc = op_multidot(h, V, V, 0))) return rc;
+            beta = sqrt(h->hres[0]);
+            rn = beta;
+            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: residual is not finite");
+            if (beta <= tol) break;
+            const double *x1[1] = { V }; double a1[1] = { 1.0 / beta };
+            if ((rc = op_lincomb(h, 1, x1, a1, V))) return rc;
+        }
+        std::fill(g.begin(), g.end(), 0.0);
+        g[0] = beta;
+        int j = 0;
+        bool done = false;
+        for (; j < m && total < maxit; j++) {
+            double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
+            if (use_pc) {
+                if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
+            } else if (use_poly) {
+                double *zj = Zq + (int64_t)j * vs;
+                if ((rc = poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
+            } else if (h->use_frozen) {
+                if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
+            } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
+            const int k = j + 1;
+            if (o->reserved == 1) {
+                // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
+                // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
+                if ((rc = op_multidot(h, w, V, k))) return rc;
+                for (int i = 0; i < k; i++) hcol[i] = h->hres[i];
+                if (!(h->hres[k] == h->hres[k])) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
+                if ((rc = op_multidot(h, w, V, k))) return rc;
+                double s2 = 0.0;
+                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
+                double hn2 = h->hres[k] - s2;          // ||w''||^2 by Pythagoras; d is O(eps) so this is accurate
+                if (hn2 < 0.0) hn2 = 0.0;
+                const double hn = sqrt(hn2);
+                if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
+                hcol[k] = hn;
+            } else {
+                // CGS2 with the second projection done algebraically (halves the Gram-Schmidt traffic):
+                //   d = V^T w and the Gram row g = V^T v_j come from ONE pass over V; with G = V^T V,
+                //   the twice-projected coefficients are c = d + (I - G) d, and
+                //   ||w - V c||^2 = ww - 2 c.d + c.G c.   One fused update pass applies c and normalises.
+                if ((rc = op_multidot_gram(h, w, V, k))) return rc;
+                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; Gm[(size_t)i * (m + 1) + j] = Gm[(size_t)j * (m + 1) + i] = h->hres[k + i]; }
+                const double ww = h->hres[2 * k];
+                if (!(ww == ww)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+                for (int i = 0; i < k; i++) {
+                    double s = 0.0;
+                    for (int l = 0; l < k; l++) s += ((i == l ? 1.0 : 0.0) - Gm[(size_t)i * (m + 1) + l]) * d[l];
+                    hcol[i] = d[i] + s;
+                }
+                double cd = 0.0, cGc = 0.0;
+                for (int i = 0; i < k; i++) {
+                    cd += hcol[i] * d[i];
+                    double s = 0.0;
+                    for (int l = 0; l < k; l++) s += Gm[(size_t)i * (m + 1) + l] * hcol[l];
+                    cGc += hcol[i] * s;
+                }
+                double hn2 = ww - 2.0 * cd + cGc;
+                double hn;
+                if (hn2 > 1e-8 * ww) {
+                    hn = sqrt(hn2);
+                    if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0 / hn))) return rc;
+                } else {
+                    // heavy cancellation (||w|| >> ||w - Vc||): apply c, then measure and project once more
+                    if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
+                    if ((rc = op_multidot(h, w, V, k))) return rc;
+                    double s2 = 0.0;
+                    for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
+                    hn2 = h->hres[k] - s2;
+                    if (hn2 < 0.0) hn2 = 0.0;
+                    hn = sqrt(hn2);
+                    if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
+                }
+                hcol[k] = hn;
+            }
+            double *Hc = &H[(size_t)(m + 1) * j];
+            for (int i = 0; i <= k; i++) Hraw[(size_t)(m + 1) * j + i] = Hc[i] = hcol[i];
+            for (int i = 0; i < j; i++) { double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1]; Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1]; Hc[i] = t; }
+            const double den = hypot(Hc[j], Hc[j + 1]);
+            cs[j] = den > 0.0 ? Hc[j] / den : 1.0;
+            sn[j] = den > 0.0 ? Hc[j + 1] / den : 0.0;
+            Hc[j] = den; Hc[j + 1] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            total++;
+            rn = fabs(g[j + 1]);
+            if (rn <= tol || hcol[k] == 0.0) { j++; done = true; break; }
+        }
+        for (int i = j - 1; i >= 0; i--) {
+            double s = g[i];
+            for (int q = i + 1; q < j; q++) s -= H[(size_t)(m + 1) * q + i] * y[q];
+            y[i] = s / H[(size_t)(m + 1) * i + i];
+        }
+        if (use_pc) {
+            if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
+            if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
+            else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
+        } else if ((rc = op_basis_axpy(h, x, use_poly ? Zq : V, j, y.data(), x_set ? 1.0 : 0.0))) return rc;
+        x_set = true;
+        if (rec_on && first && !restarted && done && j >= 1) {
+            // keep the leading vectors of this stage's Arnoldi relation where they are; the next stage builds behind them
+            ksfd_handle::RecSpace &S = h->rec[stage];
+            S.k = std::min(j, std::min(h->rec_keep, 4));
+            S.vb = vb; S.zb = zb; S.pc = pcmode;
+            for (int c = 0; c < S.k; c++)
+                for (int i = 0; i <= S.k; i++) S.H[c * (S.k + 1) + i] = Hraw[(size_t)(m + 1) * c + i];
+            S.valid = true;
+            h->rec_vtop = vb + S.k + 1;
+            h->rec_ztop = zb + (use_poly ? S.k : 0);
+        }
+        if (!first) restarted = true;
+        first = false;
+        if (done || total >= maxit) break;
+        restarted = true;
+    }
+    if (!x_set) HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
+    ls->its = total;
+    ls->rel = rn / bn;
+    if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
+    return KSFD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined GMRES: same mathematics as gmres() (CGS2 with the algebraic second projection), but the small
+// algebra of every iteration runs in a one-thread kernel on the device (k_gmres_coef) and the fused update reads its
+// coefficients from device memory, so an iteration = [J action, multi-dot, reduce(+allreduce), coef, update] with NO
+// host round trip.  The host polls the residual estimate one iteration behind (and exactly on time when the
+// extrapolated estimate says "this one converges"), so the GPU never idles and at most one iteration is wasted.
+// Pays when an iteration is latency-bound: small grids, many slab ranks.  Unpreconditioned, frozen Jacobian only.
+// ------------------------------------------------------------------------------------------------
+static int gmres_async(ksfd_handle *h, double shift, const double *b, double *x, const ksfd_step_opts *o, LinStats *ls)
+{
+    rec_reset(h);
+    const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
+    const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
+    const int64_t vs = h->vlen;
+    const int ld = h->restart_alloc + 1;
+    double *V = h->V;
+    double *dG = h->gm_dev, *dH = dG + (size_t)ld * ld, *dcs = dH + (size_t)ld * h->restart_alloc, *dsn = dcs + h->restart_alloc,
+           *dg = dsn + h->restart_alloc, *dcoef = dg + ld, *dscale = dcoef + KSFD_MAXDOT, *dmon = dscale + 1;
+    double *hmon = h->gm_host, *hH = hmon + 2 * ld, *hg = hH + (size_t)ld * h->restart_alloc;
+    int rc;
+    if ((rc = op_multidot(h, b, V, 0))) return rc;
+    const double bn = sqrt(h->hres[0]);
+    ls->its = 0; ls->rel = 0.0;
+    if (!(bn > 0.0)) {
+        if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
+        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
+        return KSFD_OK;
+    }
+    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
+    double beta = bn, rn = bn;
+    int total = 0;
+    bool first = true;
+    std::vector<double> y(m);
+    while (true) {
+        if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
+        else {
+            if ((rc = op_jvp_frozen_halo(h, x, 1, shift, V))) return rc;
+            const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
+            if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;
+            if ((rc = op_multidot(h, V, V, 0))) return rc;
+            beta = sqrt(h->hres[0]);
+            rn = beta;
+            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: residual is not finite");
+            if (beta <= tol) break;
+            const double *x1[1] = { V }; double a1[1] = { 1.0 / beta };
+            if ((rc = op_lincomb(h, 1, x1, a1, V))) return rc;
+        }
+        int jc = -1, jlast = -1, checked = -1;
+        double r1 = beta, r2 = -1.0;
+        auto poll = [&](int upto) -> int {          // read monitors (checked, upto]; sets jc when converged
+            for (int q = checked + 1; q <= upto; q++) {
+                if (hipEventSynchronize(h->gm_ev[q]) != hipSuccess) return fail(h, KSFD_EHIP, "event sync failed");
+                const double r = hmon[2 * q], hn = hmon[2 * q + 1];
+                if (!(r == r)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
+                checked = q;
+                r2 = r1; r1 = r;
+                if (r <= tol || hn == 0.0) { jc = q; return KSFD_OK; }
+            }
+            return KSFD_OK;
+        };
+        for (int j = 0; j < m && total + j < maxit; j++) {
+            double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
+            const int k = j + 1;
+            if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
+            const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
+            {
+                Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
+                if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+                else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+                else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+                else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
+            }
+            {
+                Scope sc(h, KC_REDUCE, 8.0 * (2 * k + 1) * (double)nb);
+                hipLaunchKernelGGL(k_reduce_rows, dim3(2 * k + 1), dim3(KSFD_BLOCK), 0, h->st, (const double *)h->part, nb, 0, h->dres);
+            }
+            if (h->size > 1 && h->tr->allreduce(h->dres, 2 * k + 1, 0, h->st)) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
+            hipLaunchKernelGGL(k_gmres_coef, dim3(1), dim3(64), 0, h->st, j, h->restart_alloc, beta, (const double *)h->dres, dG, dH, dcs, dsn, dg, dcoef, dscale, dmon);
+            {
+                Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
+                if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+                else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+                else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+                else VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
+            }
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(hmon + 2 * j, dmon + 2 * j, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+            HIPCHK(h, hipEventRecord(h->gm_ev[j], h->st));
+            jlast = j;
+            if ((rc = poll(j - 1))) return rc;                 // one iteration behind: the GPU already has iteration j queued
+            if (jc >= 0) break;
+            if (r2 > 0.0 && r1 * (r1 / r2) <= 1.5 * tol) {     // extrapolation says iteration j converges: look now, queue nothing more
+                if ((rc = poll(j))) return rc;
+                if (jc >= 0) break;
+            }
+        }
+        if (jc < 0 && (rc = poll(jlast))) return rc;
+        const int kused = jc >= 0 ? jc + 1 : jlast + 1;
+        total += jlast + 1;
+        HIPCHK(h, hipMemcpyAsync(hH, dH, sizeof(double) * (size_t)ld * h->restart_alloc, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(h, hipMemcpyAsync(hg, dg, sizeof(double) * ld, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(h, hipStreamSynchronize(h->st));
+        for (int i = kused - 1; i >= 0; i--) {
+            double s = hg[i];
+            for (int q = i + 1; q < kused; q++) s -= hH[(size_t)ld * q + i] * y[q];
+            y[i] = s / hH[(size_t)ld * i + i];
+        }
+        if ((rc = op_basis_axpy(h, x, V, kused, y.data(), first ? 0.0 : 1.0))) return rc;
+        first = false;
+        rn = hmon[2 * (kused - 1)];
+        if (jc >= 0 || total >= maxit) break;
+    }
+    ls->its = total;
+    ls->rel = rn / bn;
+    if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
+    return KSFD_OK;
+}

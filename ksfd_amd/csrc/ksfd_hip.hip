@@ -1,5 +1,6 @@
-// libksfd_hip.so -- host side: handle, C ABI (include/ksfd_hip.h), matrix-free GMRES and the
-// Rosenbrock-W step that stand in for petsc4py TS.step() in the reference (KSFD/ksfdts.py:211).
+// libksfd_hip.so -- C ABI (include/ksfd_hip.h) and the Rosenbrock-W step; handle, launch wrappers, multigrid and Krylov
+// solvers live in handle.hip.h / ops.hip.h / mg_host.hip.h / krylov.hip.h (one translation unit).  Together they
+// stand in for petsc4py TS.step() in the reference (KSFD/ksfdts.py:211).
 // gfx950 only.  No CPU fallback: every entry point runs HIP kernels or fails.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -16,674 +17,11 @@
 #include "mg.hip.h"
 #include "transport.h"
 
-// ------------------------------------------------------------------------------------------------
-// kernel classes for the profile
-enum { KC_RHS = 0, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE,
-       KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG };
-static const char *kc_names[KSFD_NKCLASS] = { "rhs", "jvp", "multidot", "gs_update", "lincomb", "basis_axpy",
-                                              "rosw_finish", "reduce", "gfield", "velocity", "misc", "halo", "mg" };
-extern "C" const char *ksfd_kernel_class_name(int32_t c) { return (c >= 0 && c < KSFD_NKCLASS) ? kc_names[c] : "?"; }
 
-static thread_local std::string g_create_error;
-
-struct EvPair { hipEvent_t a, b; int cls; };
-
-// one grid of the multigrid hierarchy (level 0 = the solver's own grid; see mg.hip.h)
-struct MGLevel {
-    KGeom G;
-    KPhys P;
-    KVec kv;
-    int64_t vlen = 0;
-    int nblk = 1;
-    double *coef = nullptr;    // [rho, G, G_rho, G_U..] planes (level 0 aliases the handle's)
-    double *dinv = nullptr;    // F*F planes
-    double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *Ad = nullptr, *dG = nullptr;
-    double lam_max = 2.3;
-    double ratio = 60.0;       // lambda_max/lambda_min estimate (used on the coarsest grid)
-};
-
-struct ksfd_handle {
-    ksfd_config cfg;
-    int32_t lig_group[KSFD_MAXL];
-    double lig_w[KSFD_MAXL], lig_s[KSFD_MAXL], lig_gamma[KSFD_MAXL], lig_D[KSFD_MAXL];
-    double grp_alpha[KSFD_MAXL], grp_beta[KSFD_MAXL];
-    KGeom G;
-    KPhys P;
-    KVec kv;
-    int rank = 0, size = 1, device = 0;
-    int64_t slow0 = 0;               // first owned global slow index
-    hipStream_t st = nullptr;
-    hipStream_t st_comm = nullptr;            // halo exchange stream (overlapped with interior rows)
-    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
-    bool overlap = true;
-    Transport *tr = nullptr;
-    std::string err;
-
-    // device vectors (each F*plane doubles)
-    int64_t vlen = 0;
-    double *u = nullptr, *usave = nullptr, *Z = nullptr, *bvec = nullptr, *Y = nullptr, *V = nullptr;
-    double *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *errv = nullptr;
-    double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes
-    double *coef = nullptr;                 // frozen-Jacobian coefficient planes [rho, G, G_rho, G_U..]
-    bool use_frozen = true;
-    double *flat = nullptr;                 // staging for host layouts: max(F,dim)*nloc
-    double *src[4][KSFD_MAXL + 1];          // dense source planes per stage (lazy)
-    double *part = nullptr;                 // block partials
-    double *dres = nullptr;                 // reduced results (device)
-    double *hres = nullptr;                 // pinned host mirror
-    // zero-copy hand-over of reduction results: the kernel stores into hres through its device alias and raises pub_flag
-    double *hres_dev = nullptr;
-    unsigned long long *pub_flag = nullptr, *pub_flag_dev = nullptr, pub_seq = 0;
-    unsigned int *pub_count = nullptr;
-    bool zero_copy = true;
-    int restart_alloc = 0;
-    int nblk_vec = 0;                       // grid.x of the BLAS-1 kernels
-    bool have_err = false;
-
-    // tuning
-    int use_fused = 1;
-    int yseg = 35;        // rows per wave segment, RHS kernel (measured best at 4096^2)
-    int yseg_jvp = 16;    // same for the Jacobian-action kernels
-    int zseg = 32;        // planes per wave segment, 3-D z-marching kernel
-
-    // profile
-    bool profiling = false;
-    int prof_only = -1;             // >= 0: HIP events only around launches of this kernel class
-    std::vector<EvPair> pending;
-    std::vector<hipEvent_t> pool;
-    ksfd_profile prof;
-    double bytes_acc = 0.0;
-
-    // pipelined GMRES (device-resident Hessenberg / Givens state, see gmres_async)
-    double *gm_dev = nullptr;       // [G (m+1)^2 | H (m+1)m | cs m | sn m | g m+1 | coef MAXDOT | scale 1 | mon 2(m+1)]
-    double *gm_host = nullptr;      // pinned: [mon 2(m+1) | H (m+1)m | g m+1]
-    std::vector<hipEvent_t> gm_ev;
-    int async_mode = 0;             // 0 off (default: measured no gain on one GPU, tools/async_bench.py), 1 whenever legal,
-                                    // 2 when the local problem is small
-
-    // polynomial (Chebyshev) preconditioner + flexible GMRES (see poly_setup / gmres)
-    double *Zb = nullptr;           // preconditioned basis z_j = p(A) v_j (allocated on first use)
-    double *pvec = nullptr;         // power-iteration vector for lambda_max(A)
-    double lamJ = -1.0;             // running estimate of lambda_max(-J) = lambda_max(A) - shift
-    int lam_age = 0, lam_period = 1;   // steps since the last estimate / re-estimate every lam_period steps (1..8, grows while stable)
-    int poly_deg = 0;
-    double poly_alpha[8];           // z = sum_i alpha_i (A/shift)^i v
-    double poly_shift = -1.0;
-    int poly_max_deg = 6;
-    double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
-    double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
-    float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
-    bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path)
-    bool poly_fp32 = true;          // Horner temporaries and coefficients of p(A) in fp32 storage (the outer A z_j stays fp64)
-
-    // asynchronous snapshots for writers (ksfd_snapshot_begin / _wait): layout transform on the compute stream into a
-    // device staging slot, D2H on a third stream into pinned memory while the stepper carries on
-    hipStream_t st_io = nullptr;
-    double *snap_dev[2] = { nullptr, nullptr }, *snap_host[2] = { nullptr, nullptr };
-    hipEvent_t snap_ready[2] = { nullptr, nullptr }, snap_done[2] = { nullptr, nullptr };
-    bool snap_busy[2] = { false, false };
-    int snap_next = 0;
-
-    // Krylov recycling across the four stage systems of one step (same matrix): see gmres()
-    struct RecSpace { bool valid = false; int vb = 0, zb = 0, k = 0, pc = 0; double H[20]; };   // leading (k+1) x k raw Hessenberg, ld = k+1
-    RecSpace rec[4];
-    int rec_vtop = 0, rec_ztop = 0;  // first free slot of V / Zb behind the kept vectors
-    int rec_mode = 1;                // 0 off, 1 selected earlier stages (default), 2 every earlier stage
-    int rec_keep = 3;                // leading vectors kept per stage (<= 4)
-
-    // multigrid preconditioner
-    std::vector<MGLevel> mg;
-    bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
-    double mg_shift = -1.0;      // shift the block diagonals / eigen-bounds were built for
-    bool mg_coef_valid = false;  // coarse coefficient planes match the current frozen state
-    hipGraphExec_t mg_graph = nullptr;   // captured coarse part of the V cycle (levels >= 1) for mg_graph_shift/x
-    double mg_graph_shift = -1.0, mg_graph_bytes = 0.0;
-    double *mg_graph_x = nullptr;
-    bool capturing = false, mg_use_graph = true;
-    int mg_nu = 2, mg_ncoarse = 400, mg_power_its = 8;   // smoothing sweeps, cap on coarsest-grid sweeps, power iterations
-    double mg_ratio = 6.0, mg_coarse_tol = 1e-2;
-
-    // ROSW tableau (PETSc transformed form)
-    double At[4][4], Ginv[4][4], bt[4], b2t[4], asum[4];
-};
-
-#define GAMMA_RA 4.3586652150845900e-01
-
-static int fail(ksfd_handle *h, int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (h) h->err = buf; else g_create_error = buf;
-    return code;
-}
-#define HIPCHK(h, call)                                                                                   \
-    do {                                                                                                  \
-        hipError_t e_ = (call);                                                                           \
-        if (e_ != hipSuccess) return fail(h, KSFD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-// ---- profiling helpers -------------------------------------------------------------------------
-static hipEvent_t ev_get(ksfd_handle *h)
-{
-    if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
-    hipEvent_t e;
-    hipEventCreate(&e);
-    return e;
-}
-struct Scope {
-    ksfd_handle *h; EvPair p; bool on;
-    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling && !h_->capturing && (h_->prof_only < 0 || h_->prof_only == cls))
-    {
-        h->bytes_acc += bytes;
-        h->prof.bytes[cls] += bytes;
-        h->prof.launches[cls] += 1;
-        if (on) { p.a = ev_get(h); p.b = ev_get(h); p.cls = cls; hipEventRecord(p.a, h->st); }
-    }
-    ~Scope() { if (on) { hipEventRecord(p.b, h->st); h->pending.push_back(p); } }
-};
-static void prof_resolve(ksfd_handle *h)
-{
-    if (h->pending.empty()) return;
-    hipStreamSynchronize(h->st);
-    for (auto &p : h->pending) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->prof.ms[p.cls] += ms;
-        h->pool.push_back(p.a);
-        h->pool.push_back(p.b);
-    }
-    h->pending.clear();
-}
-
-// ---- small utilities ---------------------------------------------------------------------------
-static inline dim3 vgrid(const ksfd_handle *h) { return dim3(h->nblk_vec, h->G.F); }
-static inline double vbytes(const ksfd_handle *h, double nvec) { return nvec * 8.0 * (double)h->G.F * (double)h->G.nloc; }
-
-static void build_tableau(ksfd_handle *h)
-{
-    static const double A[4][4] = { { 0, 0, 0, 0 }, { 8.7173304301691801e-01, 0, 0, 0 },
-                                    { 8.4457060015369423e-01, -1.1299064236484185e-01, 0, 0 }, { 0, 0, 1., 0 } };
-    static const double Gm[4][4] = { { GAMMA_RA, 0, 0, 0 }, { -8.7173304301691801e-01, GAMMA_RA, 0, 0 },
-                                     { -9.0338057013044082e-01, 5.4180672388095326e-02, GAMMA_RA, 0 },
-                                     { 2.4212380706095346e-01, -1.2232505839045147e+00, 5.4526025533510214e-01, GAMMA_RA } };
-    static const double b[4] = { 2.4212380706095346e-01, -1.2232505839045147e+00, 1.5452602553351020e+00, GAMMA_RA };
-    static const double b2[4] = { 3.7810903145819369e-01, -9.6042292212423178e-02, 0.5, 2.1793326075422950e-01 };
-    memset(h->Ginv, 0, sizeof h->Ginv);
-    for (int col = 0; col < 4; col++)
-        for (int i = col; i < 4; i++) {
-            double s = (i == col) ? 1.0 : 0.0;
-            for (int k = col; k < i; k++) s -= Gm[i][k] * h->Ginv[k][col];
-            h->Ginv[i][col] = s / Gm[i][i];
-        }
-    for (int i = 0; i < 4; i++) {
-        h->asum[i] = 0.0;
-        for (int j = 0; j < 4; j++) {
-            double s = 0.0;
-            for (int k = 0; k < 4; k++) s += A[i][k] * h->Ginv[k][j];
-            h->At[i][j] = s;
-            h->asum[i] += A[i][j];
-        }
-    }
-    for (int j = 0; j < 4; j++) {
-        double s = 0.0, s2 = 0.0;
-        for (int k = 0; k < 4; k++) { s += b[k] * h->Ginv[k][j]; s2 += b2[k] * h->Ginv[k][j]; }
-        h->bt[j] = s;
-        h->b2t[j] = s2;
-    }
-}
-
-static int fill_phys(ksfd_handle *h, const ksfd_config *c)
-{
-    if (c->nlig < 1 || c->nlig > KSFD_MAXL || c->ngroups < 1 || c->ngroups > KSFD_MAXL)
-        return fail(h, KSFD_EINVAL, "nlig=%d ngroups=%d outside 1..%d", c->nlig, c->ngroups, KSFD_MAXL);
-    KPhys &P = h->P;
-    memset(&P, 0, sizeof P);
-    P.nlig = c->nlig; P.ngroups = c->ngroups; P.cap_kind = c->cap_kind;
-    for (int a = 0; a < 3; a++) {
-        double sp = c->L[a] / (double)c->n[a];
-        P.inv_h[a] = 1.0 / sp;
-        P.inv_h2[a] = 1.0 / (sp * sp);
-    }
-    P.s2 = c->s2; P.rhomax = c->rhomax; P.inv_cushion = 1.0 / c->cushion; P.ms = c->maxscale * c->s2;
-    P.rhomin = c->rhomin; P.Umin = c->Umin; P.inv_rhomax = 1.0 / c->rhomax;
-    for (int l = 0; l < c->nlig; l++) {
-        if (c->lig_group[l] < 0 || c->lig_group[l] >= c->ngroups) return fail(h, KSFD_EINVAL, "lig_group[%d] out of range", l);
-        P.lig_group[l] = h->lig_group[l] = c->lig_group[l];
-        P.lig_w[l] = h->lig_w[l] = c->lig_w[l];
-        P.lig_s[l] = h->lig_s[l] = c->lig_s[l];
-        P.lig_gamma[l] = h->lig_gamma[l] = c->lig_gamma[l];
-        P.lig_D[l] = h->lig_D[l] = c->lig_D[l];
-    }
-    for (int l = c->nlig; l < KSFD_MAXL; l++) P.lig_group[l] = -1;
-    for (int q = 0; q < c->ngroups; q++) {
-        P.grp_alpha[q] = h->grp_alpha[q] = c->grp_alpha[q];
-        P.grp_beta[q] = h->grp_beta[q] = c->grp_beta[q];
-    }
-    return KSFD_OK;
-}
-
-static int alloc_d(ksfd_handle *h, double **p, int64_t n)
-{
-    if (hipMalloc((void **)p, sizeof(double) * (size_t)n) != hipSuccess) return fail(h, KSFD_ENOMEM, "hipMalloc of %lld doubles failed", (long long)n);
-    return KSFD_OK;
-}
-
-static bool fused_ok(const ksfd_handle *h)
-{
-    return h->use_fused && h->G.dim == 2 && (h->G.nx % 2 == 0) && h->G.nx >= 4 && h->G.sloc >= 4 && h->P.nlig <= 4;
-}
-
-// ---- halo exchange (DMDA globalToLocal stand-in, KSFD/ksfdsym.py:919-920) -----------------------
-static int halo(ksfd_handle *h, double *vec)
-{
-    if (h->size == 1) return KSFD_OK;
-    Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * h->G.F * (double)h->G.inner * 2.0);
-    int rc = h->tr->exchange(vec, h->G.F, h->G.plane, h->G.inner, h->G.sloc, h->G.ng, h->st);
-    if (rc) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
-    return KSFD_OK;
-}
-
-// ---- reductions to the host ------------------------------------------------------------------
-// part holds `rows` rows of `nblk` partials; result lands in h->hres[0..rows)
-// host side of the zero-copy hand-over: spin until the kernel has raised the flag (with a look at the stream now and then,
-// so that a faulted launch turns into an error instead of a hang)
-static int spin_for(ksfd_handle *h, unsigned long long seq)
-{
-    for (unsigned long long spins = 1;; spins++) {
-        if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == seq) return KSFD_OK;
-        if ((spins & 0xffff) == 0) {
-            hipError_t e = hipStreamQuery(h->st);
-            if (e == hipSuccess) {
-                if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == seq) return KSFD_OK;
-                return fail(h, KSFD_EHIP, "reduction finished without publishing its result");
-            }
-            if (e != hipErrorNotReady) return fail(h, KSFD_EHIP, "stream error while waiting for a reduction: %s", hipGetErrorString(e));
-        }
-    }
-}
-
-static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
-{
-    const bool zc = h->zero_copy && !h->capturing && rows <= 128;
-    const bool zc_here = zc && h->size == 1;
-    const unsigned long long seq = zc ? ++h->pub_seq : 0;
-    {
-        Scope sc(h, KC_REDUCE, 8.0 * rows * (double)nblk);
-        if (zc_here) hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres, h->hres_dev, h->pub_count, h->pub_flag_dev, seq);
-        else hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres);
-    }
-    if (zc_here) { HIPCHK(h, hipGetLastError()); return spin_for(h, seq); }
-    if (h->size > 1) {
-        int rc = h->tr->allreduce(h->dres, rows, op, h->st);
-        if (rc) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
-        if (h->tr->result_on_host()) { memcpy(h->hres, h->tr->host_result(), sizeof(double) * rows); return KSFD_OK; }
-        if (zc) {
-            hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, h->st, (const double *)h->dres, rows, h->hres_dev, h->pub_flag_dev, seq);
-            HIPCHK(h, hipGetLastError());
-            return spin_for(h, seq);
-        }
-    }
-    HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, sizeof(double) * rows, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(h, hipStreamSynchronize(h->st));
-    return KSFD_OK;
-}
-
-// ---- kernel wrappers ----------------------------------------------------------------------------
-#define NL_DISPATCH(nl, CALL)                                                                      \
-    switch (nl) {                                                                                  \
-    case 1: { constexpr int NL = 1; CALL; } break;                                                 \
-    case 2: { constexpr int NL = 2; CALL; } break;                                                 \
-    case 3: { constexpr int NL = 3; CALL; } break;                                                 \
-    case 4: { constexpr int NL = 4; CALL; } break;                                                 \
-    case 5: { constexpr int NL = 5; CALL; } break;                                                 \
-    default: { constexpr int NL = 6; CALL; } break;                                                \
-    }
-
-static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
-{
-    KStrips S;
-    S.nstrips = (int)((h->G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-    S.yseg = jvp ? h->yseg_jvp : h->yseg;
-    // small grids: shorter segments so that there are enough waves to fill 256 CUs (a wave costs ~1 us per row it
-    // marches; the 4 halo rows per segment are L2 hits at these sizes)
-    {
-        const long long target = jvp ? 4096 : 6144;
-        long long fit = (long long)S.nstrips * h->G.sloc / target;
-        if (fit < 2) fit = 2;
-        if (fit < S.yseg) S.yseg = (int)fit;
-    }
-    S.nseg = (int)((h->G.sloc + S.yseg - 1) / S.yseg);
-    S.seg0 = 0;
-    S.seg_stride = 1;
-    long long waves = (long long)S.nstrips * S.nseg;
-    long long nb = (waves + 3) / 4;
-    nb = (nb + 7) / 8 * 8;
-    S.nblocks = (int)nb;
-    return S;
-}
-
-static KSrc src_of(const ksfd_handle *h, int stage)
-{
-    KSrc s;
-    for (int c = 0; c <= KSFD_MAXL; c++) s.p[c] = (stage >= 0 && c < h->G.F) ? h->src[stage][c] : nullptr;
-    return s;
-}
-
-// out = f(u) (+sources of `stage`); u must have valid ghosts when size>1
-static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr)
-{
-    const KGeom &G = h->G;
-    KSrc S = src_of(h, stage);
-    if (fused_ok(h)) {
-        KStrips K = make_strips(h);
-        KComb C = cmb ? *cmb : KComb{};
-        Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out, C));
-    } else {
-        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        {
-            Scope sc(h, KC_GFIELD, 8.0 * (G.F + 1) * (double)G.plane);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, (const double *)nullptr, h->Gb, (double *)nullptr));
-        }
-        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_RHS, vbytes(h, 2) + 8.0 * (double)G.nloc);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_rhs_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->Gb, S, out));
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-// out = J(u) v (mode 0) or shift*v - J(u) v (mode 1); u and v need valid ghosts when size>1
-static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, double shift, double *out)
-{
-    const KGeom &G = h->G;
-    if (fused_ok(h)) {
-        KStrips K = make_strips(h, true);
-        Scope sc(h, KC_JVP, vbytes(h, 3));
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, v, mode, shift, out));
-    } else {
-        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        {
-            Scope sc(h, KC_GFIELD, 8.0 * (2 * G.F + 2) * (double)G.plane);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, true>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb));
-        }
-        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_JVP, vbytes(h, 3) + 16.0 * (double)G.nloc);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb, mode, shift, out));
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-// Once per step: C = [rho, G, G_rho, G_U..] of the (ghost-filled) state u
-static int op_jcoef(ksfd_handle *h, const double *u)
-{
-    const KGeom &G = h->G;
-    int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    if (!h->coef32 && h->poly_fp32 && fused_ok(h) && h->P.nlig <= 4 && G.plane % 2 == 0 && G.inner % 2 == 0 &&
-        hipMalloc((void **)&h->coef32, sizeof(float) * (size_t)(3 + h->P.nlig) * G.plane) != hipSuccess) { h->coef32 = nullptr; h->poly_fp32 = false; }
-    float *c32 = h->poly_fp32 ? h->coef32 : nullptr;
-    Scope sc(h, KC_GFIELD, (8.0 * (G.F + 3 + h->P.nlig) + (c32 ? 4.0 * (3 + h->P.nlig) : 0.0)) * (double)G.plane);
-    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef, c32));
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-// Jacobian action from the frozen coefficients (see stencil.hip.h, "Frozen-Jacobian path")
-static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift, double *out,
-                         const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
-{
-    const KGeom &G = h->G;
-    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
-    if (fused_ok(h)) {
-        KStrips K = make_strips(h, true);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta));
-    } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
-        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        {
-            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
-        }
-        K3D K;
-        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-        K.nygrp = (int)((G.ny + 3) / 4);
-        K.zseg = h->zseg;
-        {
-            long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // blocks of 4 waves
-            if (fit < 2) fit = 2;
-            if (fit < K.zseg) K.zseg = (int)fit;
-        }
-        K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
-        long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
-        K.nblocks = (int)((nb3 + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
-    } else {
-        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        {
-            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
-        }
-        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
-        // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-// Jacobian action with the halo exchange of v hidden behind the interior rows (slab ranks, 2-D fused kernel):
-//   compute stream: [interior segments]                      [two boundary segments]
-//   comm stream   :   wait(v ready) -> ghost rows of v <- ring neighbours -> signal
-// Interior segments read owned rows only; the first and last segment are the only readers of ghost rows.
-static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift, double *out,
-                              const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
-{
-    int rc;
-    const KGeom &G = h->G;
-    if (h->size == 1) return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
-    KStrips K = make_strips(h, true);
-    if (!h->overlap || !fused_ok(h) || K.nseg < 3 || h->P.nlig > 4) {
-        if ((rc = halo(h, v))) return rc;
-        return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
-    }
-    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
-    const int nseg_total = K.nseg;
-    HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
-    {
-        KStrips Ki = K;
-        Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = nseg_total - 2;
-        long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
-        Ki.nblocks = (int)((nb + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * (double)Ki.nseg / nseg_total);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Ki.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Ki, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
-    }
-    HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
-    {
-        Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * G.F * (double)G.inner * 2.0);
-        if (h->tr->exchange(v, G.F, G.plane, G.inner, G.sloc, G.ng, h->st_comm)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
-    }
-    HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
-    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
-    {
-        KStrips Kb = K;
-        Kb.seg0 = 0; Kb.seg_stride = nseg_total - 1; Kb.nseg = 2;
-        long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
-        Kb.nblocks = (int)((nb + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * 2.0 / nseg_total);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Kb.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Kb, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-// The same strip kernel with mixed storage types (fp32 coefficient copy / Horner temporaries of the polynomial
-// preconditioner).  Same overlap scheme as op_jvp_frozen_halo; a float vector travels through the double-typed transport
-// as half as many doubles (inner and plane are even on this path).
-template <typename TC, typename TV, typename TY, typename TO>
-static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const TC *C, const TV *v, int mode, double shift,
-                          TO *out, const TY *yadd, double alpha, double beta)
-{
-    const KGeom &G = h->G;
-    const double per_pt = (3.0 + h->P.nlig) * sizeof(TC) + G.F * (double)(sizeof(TV) + sizeof(TO)) + ((mode == 2 || mode == 3) ? G.F * (double)sizeof(TY) : 0.0);
-    Scope sc(h, KC_JVP, per_pt * (double)G.nloc * frac);
-    NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, TC, TV, TY, TO>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st,
-                                                                     G, h->P, K, C, (const TV *)v, mode, shift, out, yadd, alpha, beta));
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-template <typename TC, typename TV, typename TY, typename TO>
-static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shift, TO *out, const TY *yadd, double alpha, double beta)
-{
-    const KGeom &G = h->G;
-    KStrips K = make_strips(h, true);
-    if (h->size == 1) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
-    const long long scale = sizeof(double) / sizeof(TV);            // 1 for double, 2 for float
-    const bool ovl = h->overlap && K.nseg >= 3;
-    int rc;
-    if (ovl) {
-        HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
-        KStrips Ki = K;
-        Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = K.nseg - 2;
-        long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
-        Ki.nblocks = (int)((nb + 7) / 8 * 8);
-        if ((rc = jvp2d_launch_t(h, Ki, (double)Ki.nseg / K.nseg, C, v, mode, shift, out, yadd, alpha, beta))) return rc;
-        HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
-    }
-    {
-        Scope sc(h, KC_HALO, 4.0 * 2.0 * sizeof(TV) * G.F * (double)G.inner * 2.0);
-        if (h->tr->exchange(reinterpret_cast<double *>(v), G.F, G.plane / scale, G.inner / scale, G.sloc, G.ng, ovl ? h->st_comm : h->st))
-            return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
-    }
-    if (!ovl) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
-    HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
-    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
-    KStrips Kb = K;
-    Kb.seg0 = 0; Kb.seg_stride = K.nseg - 1; Kb.nseg = 2;
-    long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
-    Kb.nblocks = (int)((nb + 7) / 8 * 8);
-    return jvp2d_launch_t(h, Kb, 2.0 / K.nseg, C, v, mode, shift, out, yadd, alpha, beta);
-}
-
-// VW = 2 when every plane/offset/length is even (all accesses 16-byte aligned double2)
-static inline bool vec2(const ksfd_handle *h) { return (h->G.nloc % 2 == 0) && (h->kv.off % 2 == 0) && (h->G.plane % 2 == 0); }
-static inline dim3 vgridw(const ksfd_handle *h, int vw) { return dim3((h->nblk_vec + vw - 1) / vw, h->G.F); }
-#define VW_DISPATCH(h, CALL) do { if (vec2(h)) { constexpr int VW = 2; CALL; } else { constexpr int VW = 1; CALL; } } while (0)
-
-static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const double *a, double *out)
-{
-    KLin L;
-    for (int t = 0; t < 6; t++) { L.x[t] = t < nt ? x[t] : nullptr; L.a[t] = t < nt ? a[t] : 0.0; }
-    Scope sc(h, KC_LINCOMB, vbytes(h, nt + 1));
-    switch (nt) {
-    case 1: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<1, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 2: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<2, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 3: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<3, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 4: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 5: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<5, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    default: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<6, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-// d[0..k) = <w,V_i>, d[k] = <w,w>  -> h->hres
-static int op_multidot(ksfd_handle *h, const double *w, const double *V, int k)
-{
-    const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
-    {
-        Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
-        if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-        else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-        else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-        else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-    }
-    HIPCHK(h, hipGetLastError());
-    return reduce_rows(h, k + 1, nb, 0);
-}
-
-// d[0..k) = <w,V_i>, g[0..k) = <V_{k-1},V_i>, ww  -> h->hres[0..2k]
-static int op_multidot_gram(ksfd_handle *h, const double *w, const double *V, int k)
-{
-    const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
-    {
-        Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
-        if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-        else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-        else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-        else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
-    }
-    HIPCHK(h, hipGetLastError());
-    return reduce_rows(h, 2 * k + 1, nb, 0);
-}
-
-static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const double *coef, double scale)
-{
-    KCoef C;
-    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
-    Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
-    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
-    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
-    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
-    else VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta)
-{
-    KCoef C;
-    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
-    Scope sc(h, KC_BASISAXPY, vbytes(h, k + 1 + (beta != 0.0)));
-    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    else VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-static int op_copy(ksfd_handle *h, double *dst, const double *src)
-{
-    Scope sc(h, KC_MISC, vbytes(h, 2));
-    HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
-    return KSFD_OK;
-}
-
-// ---- host <-> device vectors -------------------------------------------------------------------
-static int upload(ksfd_handle *h, const double *host, int layout, double *dev)
-{
-    const KGeom &G = h->G;
-    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
-    HIPCHK(h, hipMemcpyAsync(h->flat, host, sizeof(double) * (size_t)G.F * G.nloc, hipMemcpyHostToDevice, h->st));
-    Scope sc(h, KC_MISC, vbytes(h, 2));
-    hipLaunchKernelGGL(k_from_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, h->flat, dev, G.plane,
-                       (long long)G.ng * G.inner);
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-static int download(ksfd_handle *h, const double *dev, int layout, double *host)
-{
-    const KGeom &G = h->G;
-    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
-    {
-        Scope sc(h, KC_MISC, vbytes(h, 2));
-        hipLaunchKernelGGL(k_to_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, dev, G.plane,
-                           (long long)G.ng * G.inner, h->flat);
-    }
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(host, h->flat, sizeof(double) * (size_t)G.F * G.nloc, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(h, hipStreamSynchronize(h->st));
-    return KSFD_OK;
-}
-
-static void mg_free(ksfd_handle *h);
-static int mg_build(ksfd_handle *h);
+#include "handle.hip.h"
+#include "ops.hip.h"
+#include "mg_host.hip.h"
+#include "krylov.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -1133,814 +471,6 @@ extern "C" int ksfd_jacobian_csr(ksfd_handle *h, int64_t *rowptr, int64_t *col, 
     return KSFD_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// multigrid preconditioner (host side; kernels and rationale in mg.hip.h)
-// ------------------------------------------------------------------------------------------------
-static void mg_free(ksfd_handle *h)
-{
-    if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
-    for (size_t l = 0; l < h->mg.size(); l++) {
-        MGLevel &L = h->mg[l];
-        double *bufs[] = { l ? L.coef : nullptr, L.dinv, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG };
-        for (double *b : bufs) if (b) hipFree(b);
-    }
-    h->mg.clear();
-    h->mg_ok = false;
-}
-
-static int mg_build(ksfd_handle *h)
-{
-    if (h->G.dim < 2) return KSFD_OK;
-    const int dim = h->G.dim;
-    int nl = h->P.nlig, F = h->G.F;
-    long long nx = h->G.nx, ny = dim == 3 ? h->G.ny : 1, rows = h->G.sloc;   // rows = local slow units (y rows in 2-D, z planes in 3-D)
-    // NOTE: every decision below must be identical on all ranks (the levels exchange halos): use sloc, never slow0.
-    // Slab r starts at unit r*sloc; it stays on the coarse grid of level l as long as sloc is divisible by 2^l.
-    KPhys P = h->P;
-    for (int l = 0;; l++) {
-        MGLevel L;
-        L.G = h->G; L.G.nx = nx;
-        if (dim == 2) { L.G.ny = rows; L.G.inner = nx; } else { L.G.ny = ny; L.G.nz = rows; L.G.inner = nx * ny; }
-        L.G.sloc = rows;
-        L.G.plane = (rows + 2 * L.G.ng) * L.G.inner; L.G.nloc = rows * L.G.inner;
-        L.P = P;
-        L.kv.plane = L.G.plane; L.kv.off = (long long)L.G.ng * L.G.inner; L.kv.nloc = L.G.nloc; L.kv.nf = F;
-        L.vlen = (int64_t)F * L.G.plane;
-        L.nblk = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
-        if (l == 0) L.coef = h->coef;
-        else if (alloc_d(h, &L.coef, (int64_t)(3 + nl) * L.G.plane) || alloc_d(h, &L.x, L.vlen) || alloc_d(h, &L.b, L.vlen)) return KSFD_ENOMEM;
-        if (alloc_d(h, &L.dinv, (int64_t)F * F * L.G.plane) || alloc_d(h, &L.r, L.vlen) || alloc_d(h, &L.d, L.vlen) ||
-            alloc_d(h, &L.Ad, L.vlen) || alloc_d(h, &L.dG, L.G.plane)) return KSFD_ENOMEM;
-        double *zero[] = { l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad };
-        for (double *z : zero) if (z) hipMemsetAsync(z, 0, sizeof(double) * (size_t)L.vlen, h->st);
-        h->mg.push_back(L);
-        // next level: every rank keeps >= 4 slow units (ghost width 2 + the 4th-order star), global grid >= 8 per axis
-        const long long rows_glob = rows * h->size;
-        if ((nx % 2) || (rows % 2) || nx / 2 < 8 || rows_glob / 2 < 8 || (h->size > 1 && rows / 2 < 4)) break;
-        if (dim == 3 && ((ny % 2) || ny / 2 < 8)) break;
-        nx /= 2; rows /= 2;
-        if (dim == 3) ny /= 2;
-        for (int a = 0; a < 3; a++) { P.inv_h[a] *= 0.5; P.inv_h2[a] *= 0.25; }
-    }
-    h->mg_ok = h->mg.size() >= 2;
-    if (h->size > 1) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
-    return KSFD_OK;
-}
-
-// transfer operators, 2-D or 3-D by the level geometry
-static void mg_launch_restrict(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *fine, double *coarse)
-{
-    int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    if (Lf.G.dim == 3)
-        hipLaunchKernelGGL(k_restrict3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
-                           fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
-    else
-        hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
-                           fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
-}
-static void mg_launch_prolong(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *coarse, double *fine)
-{
-    int nb = (int)std::min<long long>((Lf.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    if (Lf.G.dim == 3)
-        hipLaunchKernelGGL(k_prolong_add3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
-                           coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
-    else
-        hipLaunchKernelGGL(k_prolong_add2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
-                           coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
-}
-
-// ghost rows of a level vector (np field planes) from the ring neighbours
-static int mg_halo(ksfd_handle *h, MGLevel &L, double *v, int np)
-{
-    if (h->size == 1) return KSFD_OK;
-    Scope sc(h, KC_HALO, 4.0 * 8.0 * np * (double)L.G.inner * 2.0);
-    if (h->tr->exchange(v, np, L.G.plane, L.G.inner, L.G.sloc, L.G.ng, h->st)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
-    return KSFD_OK;
-}
-
-// out = J v | shift v - J v | yadd - (shift v - J v) on level L
-static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double shift, double *out, const double *yadd)
-{
-    const KGeom &G = L.G;
-    if (h->size > 1) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
-    const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
-    const double by = 8.0 * ((3 + h->P.nlig) + 2.0 * G.F + (mode == 2 ? G.F : 0)) * (double)G.nloc;
-    if (G.dim == 2 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
-        KStrips K;
-        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-        K.yseg = h->yseg_jvp;
-        {
-            long long fit = (long long)K.nstrips * G.sloc / 4096;
-            if (fit < 2) fit = 2;
-            if (fit < K.yseg) K.yseg = (int)fit;
-        }
-        K.nseg = (int)((G.sloc + K.yseg - 1) / K.yseg);
-        K.seg0 = 0; K.seg_stride = 1;
-        long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
-        K.nblocks = (int)((nb + 7) / 8 * 8);
-        Scope sc(h, cls, by);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd));
-    } else if (G.dim == 3 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
-        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        K3D K;
-        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-        K.nygrp = (int)((G.ny + 3) / 4);
-        K.zseg = h->zseg;
-        {
-            long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;
-            if (fit < 2) fit = 2;
-            if (fit < K.zseg) K.zseg = (int)fit;
-        }
-        K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
-        long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
-        K.nblocks = (int)((nb3 + 7) / 8 * 8);
-        Scope sc(h, cls, by + 8.0 * G.plane);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)L.coef, v, L.dG));
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, (const double *)L.dG, mode, shift, out, yadd));
-    } else {
-        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, cls, by + 8.0 * G.plane);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)L.coef, v, L.dG));
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, L.P, (const double *)L.coef, v, (const double *)(L.coef + G.plane), (const double *)L.dG, mode, shift, out, yadd));
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-static int mg_norm(ksfd_handle *h, MGLevel &L, const double *v, double *nrm)
-{
-    const bool v2 = (L.G.nloc % 2 == 0);
-    const int nb = v2 ? (L.nblk + 1) / 2 : L.nblk;
-    {
-        Scope sc(h, KC_MG, 8.0 * L.vlen);
-        if (v2) hipLaunchKernelGGL((k_multidot<4, 2>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.kv, v, v, L.vlen, 0, h->part);
-        else hipLaunchKernelGGL((k_multidot<4, 1>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.kv, v, v, L.vlen, 0, h->part);
-    }
-    HIPCHK(h, hipGetLastError());
-    int rc = reduce_rows(h, 1, nb, 0);
-    if (rc) return rc;
-    *nrm = sqrt(h->hres[0]);
-    return KSFD_OK;
-}
-
-// restrict coefficient planes down the hierarchy (once per frozen state)
-static int mg_restrict_coefs(ksfd_handle *h)
-{
-    const int np = 3 + h->P.nlig;
-    int rc;
-    for (size_t l = 0; l + 1 < h->mg.size(); l++) {
-        MGLevel &Lf = h->mg[l], &Lc = h->mg[l + 1];
-        {
-            Scope sc(h, KC_MG, 8.0 * np * (Lf.G.nloc + Lc.G.nloc));
-            mg_launch_restrict(h, Lf, Lc, np, Lf.coef, Lc.coef);
-        }
-        if ((rc = mg_halo(h, Lc, Lc.coef, np))) return rc;       // fine ghosts were valid; now the coarse ones are too
-    }
-    HIPCHK(h, hipGetLastError());
-    h->mg_coef_valid = true;
-    return KSFD_OK;
-}
-
-// block-diagonal inverses and Chebyshev upper bounds for this shift
-static int mg_setup_shift(ksfd_handle *h, double shift)
-{
-    int rc;
-    for (size_t l = 0; l < h->mg.size(); l++) {
-        MGLevel &L = h->mg[l];
-        const int F = L.G.F;
-        int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        {
-            Scope sc(h, KC_MG, 8.0 * (3 + h->P.nlig + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_blockdiag_inv<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G, L.P, (const double *)L.coef, shift, L.dinv));
-        }
-        HIPCHK(h, hipGetLastError());
-        // power iteration on Dinv*A: v in L.d, A v in L.Ad, Dinv A v in L.r
-        hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)L.vlen, L.d);
-        double nv = 1.0, lam = 2.0;
-        if ((rc = mg_norm(h, L, L.d, &nv))) return rc;
-        for (int it = 0; it < h->mg_power_its; it++) {
-            if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
-            {
-                Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
-                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0, L.r + L.kv.off));
-            }
-            double nw;
-            if ((rc = mg_norm(h, L, L.r, &nw))) return rc;
-            if (!(nw > 0.0) || !(nv > 0.0)) break;
-            lam = nw / nv;
-            // v <- w / |w|
-            Scope sc(h, KC_MG, 16.0 * L.vlen);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0 / nw, L.d + L.kv.off));
-            nv = 1.0;
-        }
-        L.lam_max = 1.15 * lam;
-        if (l + 1 == h->mg.size()) {
-            int nbr = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 256);
-            hipLaunchKernelGGL(k_ratio_est, dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, (long long)L.G.nloc, (const double *)(L.dinv + L.kv.off), shift, h->part);
-            if ((rc = reduce_rows(h, 1, nbr, 1))) return rc;
-            L.ratio = std::max(30.0, 1.5 * L.lam_max * h->hres[0]);
-        }
-    }
-    h->mg_shift = shift;
-    h->mg_graph_shift = -1.0;        // Chebyshev bounds changed: the captured coarse cycle is stale
-    return KSFD_OK;
-}
-
-// Chebyshev smoothing of A x = b on level L with Dinv; nu sweeps; eigen-interval [lmax/ratio, lmax]
-static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, double *x, int nu, bool zero_init, double ratio)
-{
-    // Chebyshev iteration in the "direction" form:  d_0 = Dinv r_0 / theta ; x += d_k ; r -= A d_k ;
-    // d_{k+1} = c1 d_k + c2 Dinv r.   nu sweeps = nu updates of x = nu-1 operator applications (+1 for a nonzero guess).
-    // Fusions: a zero guess writes x = d_0 directly; the last sweep folds "x += d_old + d_new" into one kernel.
-    int rc;
-    const int F = L.G.F;
-    const int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    const double lmax = L.lam_max, lmin = lmax / ratio;
-    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig1 = theta / delta;
-    const long long off = L.kv.off;     // owned rows start here inside a (ghosted) plane
-    const double *res = b;
-    if (!zero_init) {
-        if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;        // r = b - A x
-        res = L.r;
-    }
-    {
-        Scope sc(h, KC_MG, 8.0 * ((zero_init ? 3 : 2) * F + F * F) * L.G.nloc);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), res + off, 1.0 / theta, L.d + off, zero_init ? x + off : (double *)nullptr));
-    }
-    bool x_has_d = zero_init;          // x == d_0 already
-    double rho = 1.0 / sig1;
-    for (int k = 1; k < nu; k++) {
-        if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
-        const double rhon = 1.0 / (2.0 * sig1 - rho);
-        const double *rsrc = (zero_init && k == 1) ? b : L.r;             // first sweep from a zero guess: r_0 = b, never copied
-        if (k == nu - 1) {
-            Scope sc(h, KC_MG, 8.0 * (5 * F + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_last<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), x + off, rsrc + off, (const double *)(L.d + off), (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta, x_has_d ? 1 : 0));
-            x_has_d = true;
-        } else {
-            if (rsrc != L.r) HIPCHK(h, hipMemcpyAsync(L.r, b, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
-            if (x_has_d && k == 1) { /* x already holds d_0: the step kernel adds d to x, so undo by starting x at 0 */
-                HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)L.vlen, h->st));
-            }
-            Scope sc(h, KC_MG, 8.0 * (7 * F + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), x + off, L.r + off, L.d + off, (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta));
-            x_has_d = false;
-        }
-        rho = rhon;
-    }
-    if (!x_has_d) {
-        // x += d (only reached when nu == 1 with a nonzero guess, or after k_cheb_step sweeps)
-        const double *xs[2] = { x, L.d };
-        KLin LL;
-        for (int t = 0; t < 6; t++) { LL.x[t] = t < 2 ? xs[t] : nullptr; LL.a[t] = t < 2 ? 1.0 : 0.0; }
-        Scope sc(h, KC_MG, 24.0 * L.vlen);
-        hipLaunchKernelGGL((k_lincomb<2, 1>), dim3(L.nblk, F), dim3(KSFD_BLOCK), 0, h->st, L.kv, LL, x);
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x);
-
-// coarse-grid correction of level l: restrict L.r, recurse, prolong-add into x
-static int mg_coarse_correction(ksfd_handle *h, size_t l, double shift, double *x)
-{
-    int rc;
-    MGLevel &L = h->mg[l], &Lc = h->mg[l + 1];
-    if ((rc = mg_halo(h, L, L.r, L.G.F))) return rc;                 // restriction reads fine rows -1 and sloc
-    {
-        Scope sc(h, KC_MG, 8.0 * L.G.F * (L.G.nloc + Lc.G.nloc));
-        mg_launch_restrict(h, L, Lc, L.G.F, L.r, Lc.b);
-    }
-    if ((rc = mg_vcycle(h, l + 1, shift, Lc.b, Lc.x))) return rc;
-    if ((rc = mg_halo(h, Lc, Lc.x, L.G.F))) return rc;               // prolongation reads coarse row sloc_c
-    {
-        Scope sc(h, KC_MG, 8.0 * L.G.F * (2 * L.G.nloc + Lc.G.nloc));
-        mg_launch_prolong(h, L, Lc, L.G.F, Lc.x, x);
-    }
-    HIPCHK(h, hipGetLastError());
-    return KSFD_OK;
-}
-
-static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x)
-{
-    int rc;
-    MGLevel &L = h->mg[l];
-    if (l + 1 == h->mg.size()) {
-        // coarsest grid: Chebyshev over the whole spectrum, enough sweeps for a ~1e-2 reduction
-        int sweeps = (int)ceil(0.5 * sqrt(L.ratio) * log(2.0 / h->mg_coarse_tol));
-        sweeps = std::min(std::max(sweeps, 4), h->mg_ncoarse);
-        return mg_smooth(h, L, shift, b, x, sweeps, true, L.ratio);
-    }
-    if ((rc = mg_smooth(h, L, shift, b, x, h->mg_nu, true, h->mg_ratio))) return rc;
-    if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;
-    if (l == 0 && h->mg_use_graph && !h->capturing) {
-        // everything below level 0 touches only fixed buffers: capture it once per shift into a hipGraph and
-        // replay it (a V cycle has ~15 launches per level; on small grids they are pure launch latency)
-        if (!h->mg_graph || h->mg_graph_shift != shift || h->mg_graph_x != x) {
-            if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
-            hipGraph_t g = nullptr;
-            const double b0 = h->bytes_acc;
-            HIPCHK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
-            h->capturing = true;
-            rc = mg_coarse_correction(h, 0, shift, x);
-            h->capturing = false;
-            hipError_t e = hipStreamEndCapture(h->st, &g);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess || !g) return fail(h, KSFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            e = hipGraphInstantiate(&h->mg_graph, g, nullptr, nullptr, 0);
-            hipGraphDestroy(g);
-            if (e != hipSuccess) { h->mg_graph = nullptr; return fail(h, KSFD_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-            h->mg_graph_bytes = h->bytes_acc - b0;
-            h->bytes_acc = b0;
-            h->mg_graph_shift = shift;
-            h->mg_graph_x = x;
-        }
-        {
-            Scope sc(h, KC_MG, h->mg_graph_bytes);
-            HIPCHK(h, hipGraphLaunch(h->mg_graph, h->st));
-        }
-    } else if ((rc = mg_coarse_correction(h, l, shift, x))) return rc;
-    return mg_smooth(h, L, shift, b, x, h->mg_nu, false, h->mg_ratio);
-}
-
-// out = M^-1 in  (one V cycle)
-static int mg_precond(ksfd_handle *h, double shift, const double *in, double *out)
-{
-    int rc;
-    if (!h->mg_coef_valid && (rc = mg_restrict_coefs(h))) return rc;
-    if (h->mg_shift != shift && (rc = mg_setup_shift(h, shift))) return rc;
-    return mg_vcycle(h, 0, shift, in, out);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Polynomial preconditioner.  In the non-stiff regime (h*gamma*lambda_max(J) of order 1..10, the regime of the
-// headline benchmark) plain GMRES needs ~7 iterations per stage and spends most of its time in Gram-Schmidt, whose
-// traffic grows with the square of the iteration count.  z = p(A) v with p the degree-d Chebyshev approximation of
-// 1/lambda on [a, b] (spectrum of A/shift: a ~ 1, b = 1 + lambda_max(-J)/shift) costs d Jacobian actions with a fused
-// Horner epilogue (out = alpha*v + beta*A t, no extra pass) and cuts the outer iterations to 2-3: same number of
-// Jacobian actions, a fraction of the Gram-Schmidt passes.  Used through flexible GMRES (Z basis kept), so the
-// solution update needs no extra preconditioner application.
-// ------------------------------------------------------------------------------------------------
-static int est_lambda_max(ksfd_handle *h, double shift, int nits)
-{
-    int rc;
-    if (!h->pvec) {
-        if (alloc_d(h, &h->pvec, h->vlen)) return KSFD_ENOMEM;
-        int nb = (int)std::min<long long>((h->vlen + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)h->vlen, h->pvec);
-        if ((rc = op_multidot(h, h->pvec, h->pvec, 0))) return rc;
-        const double n0 = sqrt(h->hres[0]);
-        const double *xs[1] = { h->pvec }; double a[1] = { 1.0 / n0 };
-        if ((rc = op_lincomb(h, 1, xs, a, h->pvec))) return rc;
-    }
-    double lamA = 0.0;
-    for (int it = 0; it < nits; it++) {
-        if ((rc = op_jvp_frozen_halo(h, h->pvec, 1, shift, h->t3))) return rc;
-        if ((rc = op_multidot(h, h->t3, h->t3, 0))) return rc;
-        lamA = sqrt(h->hres[0]);
-        if (!(lamA > 0.0) || lamA != lamA) return fail(h, KSFD_ENAN, "power iteration on the Jacobian broke down");
-        const double *xs[1] = { h->t3 }; double a[1] = { 1.0 / lamA };
-        if ((rc = op_lincomb(h, 1, xs, a, h->pvec))) return rc;
-    }
-    const double est = lamA - shift;
-    h->lamJ = est > 0.0 ? est : 0.0;
-    return KSFD_OK;
-}
-
-// coefficients of p for this shift; degree 0 = "do not precondition"
-static void poly_setup(ksfd_handle *h, double shift)
-{
-    const double a = 0.97, b = 1.0 + 1.15 * h->lamJ / shift;      // spectrum of A/shift (power iteration converges from below: +15 %)
-    h->poly_shift = shift;
-    h->poly_deg = 0;
-    const double kappa = b / a;
-    if (kappa < 1.3) return;                                       // GMRES alone needs <= 3 iterations
-    const double rc_ = (sqrt(kappa) - 1.0) / (sqrt(kappa) + 1.0);
-    int d = (int)ceil(log(h->poly_target) / log(rc_)) - 1;         // residual polynomial of degree d+1: ~2 rc^(d+1) <= 2*target
-    d = std::min(std::max(d, 1), std::max(h->poly_max_deg, 1));
-    // r(l) = T_{d+1}(mu(l)) / T_{d+1}(mu(0)), mu(l) = m0 + m1 l;  p(l) = (1 - r(l)) / l
-    const int n = d + 1;
-    double m0 = (b + a) / (b - a), m1 = -2.0 / (b - a);
-    double Tp[10] = { 1.0 }, Tc[10] = { m0, m1 }, Tn[10];
-    int degc = 1;
-    for (int k = 1; k < n; k++) {
-        for (int i = 0; i < 10; i++) Tn[i] = 0.0;
-        for (int i = 0; i <= degc; i++) { Tn[i] += 2.0 * m0 * Tc[i]; Tn[i + 1] += 2.0 * m1 * Tc[i]; }
-        for (int i = 0; i <= degc - 1; i++) Tn[i] -= Tp[i];
-        for (int i = 0; i < 10; i++) { Tp[i] = Tc[i]; Tc[i] = Tn[i]; }
-        degc++;
-    }
-    const double t0 = Tc[0];                                       // T_n(mu(0))
-    for (int i = 0; i <= d; i++) h->poly_alpha[i] = -(Tc[i + 1] / t0) / shift;   // p_i = -r_{i+1}; the 1/shift turns p(A/shift) into ~A^-1
-    h->poly_deg = d;
-}
-
-// z = sum_i alpha_i (A/shift)^i v  by Horner, one fused Jacobian action per degree
-static int poly_apply(ksfd_handle *h, double shift, double *v, double *z)
-{
-    int rc;
-    const int d = h->poly_deg;
-    const double *al = h->poly_alpha;
-    if (h->poly_fp32 && h->coef32 && fused_ok(h)) {
-        // mixed precision: the Horner temporaries and the coefficient planes live in fp32 (half the traffic of every
-        // application but the arithmetic stays fp64); v is read and z written in fp64.  p(A) becomes a slightly
-        // different fixed linear operator, which flexible GMRES does not care about: w_j = A z_j is computed in fp64
-        // from the stored z_j, so the Arnoldi relation and the solution keep full accuracy.
-        const float *C = h->coef32;
-        float *tf[2] = { reinterpret_cast<float *>(h->t1), reinterpret_cast<float *>(h->t2) };
-        const double *nod = nullptr;
-        if (d == 1) return jvp2d_halo_t<float, double, double, double>(h, C, v, 4, shift, z, nod, al[0], al[1] / shift);
-        if ((rc = jvp2d_halo_t<float, double, double, float>(h, C, v, 4, shift, tf[0], nod, al[d - 1], al[d] / shift))) return rc;
-        int cur32 = 0;
-        for (int i = d - 2; i >= 1; i--) {
-            if ((rc = jvp2d_halo_t<float, float, double, float>(h, C, tf[cur32], 3, shift, tf[cur32 ^ 1], (const double *)v, al[i], 1.0 / shift))) return rc;
-            cur32 ^= 1;
-        }
-        return jvp2d_halo_t<float, float, double, double>(h, C, tf[cur32], 3, shift, z, (const double *)v, al[0], 1.0 / shift);
-    }
-    double *tmp[2] = { h->t1, h->t2 };
-    // t_{d-1} = alpha_{d-1} v + (alpha_d/shift) A v
-    double *cur = (d == 1) ? z : tmp[0];
-    if ((rc = op_jvp_frozen_halo(h, v, 4, shift, cur, nullptr, al[d - 1], al[d] / shift))) return rc;
-    int flip = 1;
-    for (int i = d - 2; i >= 0; i--) {
-        double *nxt = (i == 0) ? z : tmp[flip];
-        if ((rc = op_jvp_frozen_halo(h, cur, 3, shift, nxt, v, al[i], 1.0 / shift))) return rc;
-        cur = nxt;
-        flip ^= 1;
-    }
-    return KSFD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// matrix-free GMRES(m) for (shift I - J(u)) x = b, x0 = 0  -- replaces -ksp_type preonly -pc_type lu
-// (options84:58-60).  Classical Gram-Schmidt applied twice (CGS2), one fused multi-dot + one fused
-// update kernel per pass; the new vector's norm comes from the second pass by Pythagoras.
-// ------------------------------------------------------------------------------------------------
-struct LinStats { int its; double rel; };
-
-static void rec_reset(ksfd_handle *h)
-{
-    for (auto &r : h->rec) r.valid = false;
-    h->rec_vtop = h->rec_ztop = 0;
-}
-
-// Least squares min ||g - H y|| for a small upper-Hessenberg H ((k+1) x k, column-major, ld = k+1); also returns H y.
-static void hess_lsq(const double *H, int k, const double *g, double *y, double *Hy)
-{
-    double R[20], q[5];
-    const int ld = k + 1;
-    for (int i = 0; i < ld * k; i++) R[i] = H[i];
-    for (int i = 0; i <= k; i++) q[i] = g[i];
-    for (int j = 0; j < k; j++) {
-        const double a = R[j * ld + j], b = R[j * ld + j + 1], den = hypot(a, b);
-        const double c = den > 0.0 ? a / den : 1.0, sn = den > 0.0 ? b / den : 0.0;
-        for (int l = j; l < k; l++) {
-            const double t = c * R[l * ld + j] + sn * R[l * ld + j + 1];
-            R[l * ld + j + 1] = -sn * R[l * ld + j] + c * R[l * ld + j + 1];
-            R[l * ld + j] = t;
-        }
-        const double t = c * q[j] + sn * q[j + 1];
-        q[j + 1] = -sn * q[j] + c * q[j + 1];
-        q[j] = t;
-    }
-    for (int i = k - 1; i >= 0; i--) {
-        double t = q[i];
-        for (int l = i + 1; l < k; l++) t -= R[l * ld + i] * y[l];
-        y[i] = R[i * ld + i] != 0.0 ? t / R[i * ld + i] : 0.0;
-    }
-    for (int i = 0; i <= k; i++) {
-        double t = 0.0;
-        for (int l = 0; l < k; l++) t += H[l * ld + i] * y[l];
-        Hy[i] = t;
-    }
-}
-
-// stage >= 0: Krylov recycling.  The four stage systems of a step share the matrix, and their right-hand sides are
-// nearly linear images of one another (b_i = f(u + sum a_ij Y_j) - sum c_ij Y_j/h with f almost linear over a step), so
-// the leading Arnoldi vectors of an earlier stage (A Z_s = V_s H_s, kept in place at the front of V / Zb) already span
-// most of the new solution: x0 = Z_s y with y = argmin ||V_s^T r - H_s y||, r <- r - V_s H_s y, one space after the
-// other, costs ~5 vector passes per kept vector and removes 1-2 of the 3-4 outer iterations of stages 2-4 (each
-// (d+1) Jacobian actions + Gram-Schmidt).  The iteration then continues on the true residual with the same stopping
-// test, so the result is the same to the solver tolerance.  stage < 0: plain solve from x0 = 0.
-static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
-                 const ksfd_step_opts *o, LinStats *ls, int pcmode, int stage = -1)
-{
-    const bool use_pc = pcmode == 1;       // multigrid, right preconditioning
-    const bool use_poly = pcmode == 2;     // Chebyshev polynomial, flexible GMRES (z_j kept in Zb)
-    // use_pc: right preconditioning with one multigrid V cycle, w = A (M^-1 v_j), x = M^-1 (V y)
-    auto apply_A = [&](const double *vin, double *wout) -> int {
-        return h->use_frozen ? op_jvp_frozen(h, vin, 1, shift, wout) : op_jvp(h, ustate, vin, 1, shift, wout);
-    };
-    const int m_opt = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
-    const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
-    const int64_t vs = h->vlen;
-    bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen;
-    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 10) { if (stage != 0) rec_on = false; rec_reset(h); }
-    const int vb = rec_on ? h->rec_vtop : 0, zb = rec_on ? h->rec_ztop : 0;
-    const int m = std::min(m_opt, h->restart_alloc - vb);
-    double *V = h->V + (int64_t)vb * vs;
-    double *Zq = use_poly ? h->Zb + (int64_t)zb * vs : nullptr;
-    int rc;
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), Hraw((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2), Gm((size_t)(m + 1) * (m + 1), 0.0);
-    if ((rc = op_multidot(h, b, V, 0))) return rc;
-    const double bn = sqrt(h->hres[0]);
-    ls->its = 0; ls->rel = 0.0;
-    if (!(bn > 0.0)) {
-        if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
-        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
-        return KSFD_OK;
-    }
-    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
-    double beta = bn, rn = bn;
-    int total = 0;
-    bool first = true;          // the residual of the current x is at hand (rsrc, norm beta): no A x needed
-    bool x_set = false;         // x holds an iterate (else it is taken as 0 and overwritten)
-    bool restarted = false;
-    const double *rsrc = b;
-    if (rec_on && stage > 0) {
-        static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
-        for (int q = 0; q < stage; q++) {
-            bool use = h->rec_mode == 2;
-            for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
-            const ksfd_handle::RecSpace &S = h->rec[q];
-            if (!use || !S.valid || S.pc != pcmode) continue;
-            const double *Vs = h->V + (int64_t)S.vb * vs;
-            const double *Zs = use_poly ? h->Zb + (int64_t)S.zb * vs : Vs;
-            double gq[5], yq[4], Hy[5], neg[5];
-            if ((rc = op_multidot(h, rsrc, Vs, S.k + 1))) return rc;
-            for (int i = 0; i <= S.k; i++) gq[i] = h->hres[i];
-            hess_lsq(S.H, S.k, gq, yq, Hy);
-            if (use_pc) {
-                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
-                if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
-                else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
-            } else if ((rc = op_basis_axpy(h, x, Zs, S.k, yq, x_set ? 1.0 : 0.0))) return rc;
-            x_set = true;
-            for (int i = 0; i <= S.k; i++) neg[i] = -Hy[i];
-            if (rsrc == b) {
-                const double *xs[6] = { b }; double a[6] = { 1.0 };
-                for (int i = 0; i <= S.k; i++) { xs[i + 1] = Vs + (int64_t)i * vs; a[i + 1] = neg[i]; }
-                if ((rc = op_lincomb(h, S.k + 2, xs, a, h->t3))) return rc;
-                rsrc = h->t3;
-            } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0))) return rc;
-        }
-        if (x_set) {
-            if ((rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
-            beta = rn = sqrt(h->hres[0]);
-            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: projected residual is not finite");
-        }
-    }
-    while (true) {
-        if (first && beta <= tol) break;                       // the recycled spaces already hold the solution
-        // V0 = r / beta
-        if (first) { const double *xs[1] = { rsrc }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
-        else {
-            if ((rc = halo(h, x)) || (rc = apply_A(x, V))) return rc;     // V0 = A x
-            const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
-            if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;                                  // r = b - A x
-            if ((rc = op_multidot(h, V, V, 0))) return rc;
-            beta = sqrt(h->hres[0]);
-            rn = beta;
-            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: residual is not finite");
-            if (beta <= tol) break;
-            const double *x1[1] = { V }; double a1[1] = { 1.0 / beta };
-            if ((rc = op_lincomb(h, 1, x1, a1, V))) return rc;
-        }
-        std::fill(g.begin(), g.end(), 0.0);
-        g[0] = beta;
-        int j = 0;
-        bool done = false;
-        for (; j < m && total < maxit; j++) {
-            double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
-            if (use_pc) {
-                if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
-            } else if (use_poly) {
-                double *zj = Zq + (int64_t)j * vs;
-                if ((rc = poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
-            } else if (h->use_frozen) {
-                if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
-            } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
-            const int k = j + 1;
-            if (o->reserved == 1) {
-                // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
-                // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
-                if ((rc = op_multidot(h, w, V, k))) return rc;
-                for (int i = 0; i < k; i++) hcol[i] = h->hres[i];
-                if (!(h->hres[k] == h->hres[k])) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
-                if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
-                if ((rc = op_multidot(h, w, V, k))) return rc;
-                double s2 = 0.0;
-                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
-                double hn2 = h->hres[k] - s2;          // ||w''||^2 by Pythagoras; d is O(eps) so this is accurate
-                if (hn2 < 0.0) hn2 = 0.0;
-                const double hn = sqrt(hn2);
-                if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
-                hcol[k] = hn;
-            } else {
-                // CGS2 with the second projection done algebraically (halves the Gram-Schmidt traffic):
-                //   d = V^T w and the Gram row g = V^T v_j come from ONE pass over V; with G = V^T V,
-                //   the twice-projected coefficients are c = d + (I - G) d, and
-                //   ||w - V c||^2 = ww - 2 c.d + c.G c.   One fused update pass applies c and normalises.
-                if ((rc = op_multidot_gram(h, w, V, k))) return rc;
-                for (int i = 0; i < k; i++) { d[i] = h->hres[i]; Gm[(size_t)i * (m + 1) + j] = Gm[(size_t)j * (m + 1) + i] = h->hres[k + i]; }
-                const double ww = h->hres[2 * k];
-                if (!(ww == ww)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
-                for (int i = 0; i < k; i++) {
-                    double s = 0.0;
-                    for (int l = 0; l < k; l++) s += ((i == l ? 1.0 : 0.0) - Gm[(size_t)i * (m + 1) + l]) * d[l];
-                    hcol[i] = d[i] + s;
-                }
-                double cd = 0.0, cGc = 0.0;
-                for (int i = 0; i < k; i++) {
-                    cd += hcol[i] * d[i];
-                    double s = 0.0;
-                    for (int l = 0; l < k; l++) s += Gm[(size_t)i * (m + 1) + l] * hcol[l];
-                    cGc += hcol[i] * s;
-                }
-                double hn2 = ww - 2.0 * cd + cGc;
-                double hn;
-                if (hn2 > 1e-8 * ww) {
-                    hn = sqrt(hn2);
-                    if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0 / hn))) return rc;
-                } else {
-                    // heavy cancellation (||w|| >> ||w - Vc||): apply c, then measure and project once more
-                    if ((rc = op_gs_update(h, w, V, k, hcol.data(), 1.0))) return rc;
-                    if ((rc = op_multidot(h, w, V, k))) return rc;
-                    double s2 = 0.0;
-                    for (int i = 0; i < k; i++) { d[i] = h->hres[i]; hcol[i] += d[i]; s2 += d[i] * d[i]; }
-                    hn2 = h->hres[k] - s2;
-                    if (hn2 < 0.0) hn2 = 0.0;
-                    hn = sqrt(hn2);
-                    if ((rc = op_gs_update(h, w, V, k, d.data(), hn > 0.0 ? 1.0 / hn : 0.0))) return rc;
-                }
-                hcol[k] = hn;
-            }
-            double *Hc = &H[(size_t)(m + 1) * j];
-            for (int i = 0; i <= k; i++) Hraw[(size_t)(m + 1) * j + i] = Hc[i] = hcol[i];
-            for (int i = 0; i < j; i++) { double t = cs[i] * Hc[i] + sn[i] * Hc[i + 1]; Hc[i + 1] = -sn[i] * Hc[i] + cs[i] * Hc[i + 1]; Hc[i] = t; }
-            const double den = hypot(Hc[j], Hc[j + 1]);
-            cs[j] = den > 0.0 ? Hc[j] / den : 1.0;
-            sn[j] = den > 0.0 ? Hc[j + 1] / den : 0.0;
-            Hc[j] = den; Hc[j + 1] = 0.0;
-            g[j + 1] = -sn[j] * g[j];
-            g[j] = cs[j] * g[j];
-            total++;
-            rn = fabs(g[j + 1]);
-            if (rn <= tol || hcol[k] == 0.0) { j++; done = true; break; }
-        }
-        for (int i = j - 1; i >= 0; i--) {
-            double s = g[i];
-            for (int q = i + 1; q < j; q++) s -= H[(size_t)(m + 1) * q + i] * y[q];
-            y[i] = s / H[(size_t)(m + 1) * i + i];
-        }
-        if (use_pc) {
-            if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
-            if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
-            else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
-        } else if ((rc = op_basis_axpy(h, x, use_poly ? Zq : V, j, y.data(), x_set ? 1.0 : 0.0))) return rc;
-        x_set = true;
-        if (rec_on && first && !restarted && done && j >= 1) {
-            // keep the leading vectors of this stage's Arnoldi relation where they are; the next stage builds behind them
-            ksfd_handle::RecSpace &S = h->rec[stage];
-            S.k = std::min(j, std::min(h->rec_keep, 4));
-            S.vb = vb; S.zb = zb; S.pc = pcmode;
-            for (int c = 0; c < S.k; c++)
-                for (int i = 0; i <= S.k; i++) S.H[c * (S.k + 1) + i] = Hraw[(size_t)(m + 1) * c + i];
-            S.valid = true;
-            h->rec_vtop = vb + S.k + 1;
-            h->rec_ztop = zb + (use_poly ? S.k : 0);
-        }
-        if (!first) restarted = true;
-        first = false;
-        if (done || total >= maxit) break;
-        restarted = true;
-    }
-    if (!x_set) HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
-    ls->its = total;
-    ls->rel = rn / bn;
-    if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
-    return KSFD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pipelined GMRES: same mathematics as gmres() (CGS2 with the algebraic second projection), but the small
-// algebra of every iteration runs in a one-thread kernel on the device (k_gmres_coef) and the fused update reads its
-// coefficients from device memory, so an iteration = [J action, multi-dot, reduce(+allreduce), coef, update] with NO
-// host round trip.  The host polls the residual estimate one iteration behind (and exactly on time when the
-// extrapolated estimate says "this one converges"), so the GPU never idles and at most one iteration is wasted.
-// Pays when an iteration is latency-bound: small grids, many slab ranks.  Unpreconditioned, frozen Jacobian only.
-// ------------------------------------------------------------------------------------------------
-static int gmres_async(ksfd_handle *h, double shift, const double *b, double *x, const ksfd_step_opts *o, LinStats *ls)
-{
-    rec_reset(h);
-    const int m = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
-    const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
-    const int64_t vs = h->vlen;
-    const int ld = h->restart_alloc + 1;
-    double *V = h->V;
-    double *dG = h->gm_dev, *dH = dG + (size_t)ld * ld, *dcs = dH + (size_t)ld * h->restart_alloc, *dsn = dcs + h->restart_alloc,
-           *dg = dsn + h->restart_alloc, *dcoef = dg + ld, *dscale = dcoef + KSFD_MAXDOT, *dmon = dscale + 1;
-    double *hmon = h->gm_host, *hH = hmon + 2 * ld, *hg = hH + (size_t)ld * h->restart_alloc;
-    int rc;
-    if ((rc = op_multidot(h, b, V, 0))) return rc;
-    const double bn = sqrt(h->hres[0]);
-    ls->its = 0; ls->rel = 0.0;
-    if (!(bn > 0.0)) {
-        if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
-        HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
-        return KSFD_OK;
-    }
-    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
-    double beta = bn, rn = bn;
-    int total = 0;
-    bool first = true;
-    std::vector<double> y(m);
-    while (true) {
-        if (first) { const double *xs[1] = { b }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
-        else {
-            if ((rc = op_jvp_frozen_halo(h, x, 1, shift, V))) return rc;
-            const double *xs[2] = { b, V }; double a[2] = { 1.0, -1.0 };
-            if ((rc = op_lincomb(h, 2, xs, a, V))) return rc;
-            if ((rc = op_multidot(h, V, V, 0))) return rc;
-            beta = sqrt(h->hres[0]);
-            rn = beta;
-            if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: residual is not finite");
-            if (beta <= tol) break;
-            const double *x1[1] = { V }; double a1[1] = { 1.0 / beta };
-            if ((rc = op_lincomb(h, 1, x1, a1, V))) return rc;
-        }
-        int jc = -1, jlast = -1, checked = -1;
-        double r1 = beta, r2 = -1.0;
-        auto poll = [&](int upto) -> int {          // read monitors (checked, upto]; sets jc when converged
-            for (int q = checked + 1; q <= upto; q++) {
-                if (hipEventSynchronize(h->gm_ev[q]) != hipSuccess) return fail(h, KSFD_EHIP, "event sync failed");
-                const double r = hmon[2 * q], hn = hmon[2 * q + 1];
-                if (!(r == r)) return fail(h, KSFD_ENAN, "GMRES: Krylov vector is not finite");
-                checked = q;
-                r2 = r1; r1 = r;
-                if (r <= tol || hn == 0.0) { jc = q; return KSFD_OK; }
-            }
-            return KSFD_OK;
-        };
-        for (int j = 0; j < m && total + j < maxit; j++) {
-            double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
-            const int k = j + 1;
-            if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
-            const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
-            {
-                Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
-                if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
-                else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
-                else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
-                else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)w, (const double *)V, h->vlen, k, h->part));
-            }
-            {
-                Scope sc(h, KC_REDUCE, 8.0 * (2 * k + 1) * (double)nb);
-                hipLaunchKernelGGL(k_reduce_rows, dim3(2 * k + 1), dim3(KSFD_BLOCK), 0, h->st, (const double *)h->part, nb, 0, h->dres);
-            }
-            if (h->size > 1 && h->tr->allreduce(h->dres, 2 * k + 1, 0, h->st)) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
-            hipLaunchKernelGGL(k_gmres_coef, dim3(1), dim3(64), 0, h->st, j, h->restart_alloc, beta, (const double *)h->dres, dG, dH, dcs, dsn, dg, dcoef, dscale, dmon);
-            {
-                Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
-                if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
-                else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
-                else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
-                else VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update_dev<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, (const double *)V, h->vlen, k, (const double *)dcoef, (const double *)dscale));
-            }
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipMemcpyAsync(hmon + 2 * j, dmon + 2 * j, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-            HIPCHK(h, hipEventRecord(h->gm_ev[j], h->st));
-            jlast = j;
-            if ((rc = poll(j - 1))) return rc;                 // one iteration behind: the GPU already has iteration j queued
-            if (jc >= 0) break;
-            if (r2 > 0.0 && r1 * (r1 / r2) <= 1.5 * tol) {     // extrapolation says iteration j converges: look now, queue nothing more
-                if ((rc = poll(j))) return rc;
-                if (jc >= 0) break;
-            }
-        }
-        if (jc < 0 && (rc = poll(jlast))) return rc;
-        const int kused = jc >= 0 ? jc + 1 : jlast + 1;
-        total += jlast + 1;
-        HIPCHK(h, hipMemcpyAsync(hH, dH, sizeof(double) * (size_t)ld * h->restart_alloc, hipMemcpyDeviceToHost, h->st));
-        HIPCHK(h, hipMemcpyAsync(hg, dg, sizeof(double) * ld, hipMemcpyDeviceToHost, h->st));
-        HIPCHK(h, hipStreamSynchronize(h->st));
-        for (int i = kused - 1; i >= 0; i--) {
-            double s = hg[i];
-            for (int q = i + 1; q < kused; q++) s -= hH[(size_t)ld * q + i] * y[q];
-            y[i] = s / hH[(size_t)ld * i + i];
-        }
-        if ((rc = op_basis_axpy(h, x, V, kused, y.data(), first ? 0.0 : 1.0))) return rc;
-        first = false;
-        rn = hmon[2 * (kused - 1)];
-        if (jc >= 0 || total >= maxit) break;
-    }
-    ls->its = total;
-    ls->rel = rn / bn;
-    if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
-    return KSFD_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 extern "C" void ksfd_default_step_opts(ksfd_step_opts *o)

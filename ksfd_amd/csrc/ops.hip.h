@@ -1,0 +1,410 @@
+// libksfd_hip.so -- halo exchange, host-visible reductions, launch wrappers of every kernel class, host<->device layouts
+// (part of the single translation unit ksfd_hip.hip; included from there in this order:
+//  handle.hip.h, ops.hip.h, mg_host.hip.h, krylov.hip.h)
+#pragma once
+// ---- halo exchange (DMDA globalToLocal stand-in, KSFD/ksfdsym.py:919-920) -----------------------
+static int halo(ksfd_handle *h, double *vec)
+{
+    if (h->size == 1) return KSFD_OK;
+    Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * h->G.F * (double)h->G.inner * 2.0);
+    int rc = h->tr->exchange(vec, h->G.F, h->G.plane, h->G.inner, h->G.sloc, h->G.ng, h->st);
+    if (rc) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    return KSFD_OK;
+}
+
+// ---- reductions to the host ------------------------------------------------------------------
+// part holds `rows` rows of `nblk` partials; result lands in h->hres[0..rows)
+// host side of the zero-copy hand-over: spin until the kernel has raised the flag (with a look at the stream now and then,
+// so that a faulted launch turns into an error instead of a hang)
+static int spin_for(ksfd_handle *h, unsigned long long seq)
+{
+    for (unsigned long long spins = 1;; spins++) {
+        if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == seq) return KSFD_OK;
+        if ((spins & 0xffff) == 0) {
+            hipError_t e = hipStreamQuery(h->st);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(h->pub_flag, __ATOMIC_ACQUIRE) == seq) return KSFD_OK;
+                return fail(h, KSFD_EHIP, "reduction finished without publishing its result");
+            }
+            if (e != hipErrorNotReady) return fail(h, KSFD_EHIP, "stream error while waiting for a reduction: %s", hipGetErrorString(e));
+        }
+    }
+}
+
+static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
+{
+    const bool zc = h->zero_copy && !h->capturing && rows <= 128;
+    const bool zc_here = zc && h->size == 1;
+    const unsigned long long seq = zc ? ++h->pub_seq : 0;
+    {
+        Scope sc(h, KC_REDUCE, 8.0 * rows * (double)nblk);
+        if (zc_here) hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres, h->hres_dev, h->pub_count, h->pub_flag_dev, seq);
+        else hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres);
+    }
+    if (zc_here) { HIPCHK(h, hipGetLastError()); return spin_for(h, seq); }
+    if (h->size > 1) {
+        int rc = h->tr->allreduce(h->dres, rows, op, h->st);
+        if (rc) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
+        if (h->tr->result_on_host()) { memcpy(h->hres, h->tr->host_result(), sizeof(double) * rows); return KSFD_OK; }
+        if (zc) {
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(128), 0, h->st, (const double *)h->dres, rows, h->hres_dev, h->pub_flag_dev, seq);
+            HIPCHK(h, hipGetLastError());
+            return spin_for(h, seq);
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->hres, h->dres, sizeof(double) * rows, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
+
+// ---- kernel wrappers ----------------------------------------------------------------------------
+#define NL_DISPATCH(nl, CALL)                                                                      \
+    switch (nl) {                                                                                  \
+    case 1: { constexpr int NL = 1; CALL; } break;                                                 \
+    case 2: { constexpr int NL = 2; CALL; } break;                                                 \
+    case 3: { constexpr int NL = 3; CALL; } break;                                                 \
+    case 4: { constexpr int NL = 4; CALL; } break;                                                 \
+    case 5: { constexpr int NL = 5; CALL; } break;                                                 \
+    default: { constexpr int NL = 6; CALL; } break;                                                \
+    }
+
+static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
+{
+    KStrips S;
+    S.nstrips = (int)((h->G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+    S.yseg = jvp ? h->yseg_jvp : h->yseg;
+    // small grids: shorter segments so that there are enough waves to fill 256 CUs (a wave costs ~1 us per row it
+    // marches; the 4 halo rows per segment are L2 hits at these sizes)
+    {
+        const long long target = jvp ? 4096 : 6144;
+        long long fit = (long long)S.nstrips * h->G.sloc / target;
+        if (fit < 2) fit = 2;
+        if (fit < S.yseg) S.yseg = (int)fit;
+    }
+    S.nseg = (int)((h->G.sloc + S.yseg - 1) / S.yseg);
+    S.seg0 = 0;
+    S.seg_stride = 1;
+    long long waves = (long long)S.nstrips * S.nseg;
+    long long nb = (waves + 3) / 4;
+    nb = (nb + 7) / 8 * 8;
+    S.nblocks = (int)nb;
+    return S;
+}
+
+static KSrc src_of(const ksfd_handle *h, int stage)
+{
+    KSrc s;
+    for (int c = 0; c <= KSFD_MAXL; c++) s.p[c] = (stage >= 0 && c < h->G.F) ? h->src[stage][c] : nullptr;
+    return s;
+}
+
+// out = f(u) (+sources of `stage`); u must have valid ghosts when size>1
+static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr)
+{
+    const KGeom &G = h->G;
+    KSrc S = src_of(h, stage);
+    if (fused_ok(h)) {
+        KStrips K = make_strips(h);
+        KComb C = cmb ? *cmb : KComb{};
+        Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out, C));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (G.F + 1) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, (const double *)nullptr, h->Gb, (double *)nullptr));
+        }
+        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_RHS, vbytes(h, 2) + 8.0 * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_rhs_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->Gb, S, out));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// out = J(u) v (mode 0) or shift*v - J(u) v (mode 1); u and v need valid ghosts when size>1
+static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, double shift, double *out)
+{
+    const KGeom &G = h->G;
+    if (fused_ok(h)) {
+        KStrips K = make_strips(h, true);
+        Scope sc(h, KC_JVP, vbytes(h, 3));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, v, mode, shift, out));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 * G.F + 2) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, true>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb));
+        }
+        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_JVP, vbytes(h, 3) + 16.0 * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb, mode, shift, out));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// Once per step: C = [rho, G, G_rho, G_U..] of the (ghost-filled) state u
+static int op_jcoef(ksfd_handle *h, const double *u)
+{
+    const KGeom &G = h->G;
+    int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    if (!h->coef32 && h->poly_fp32 && fused_ok(h) && h->P.nlig <= 4 && G.plane % 2 == 0 && G.inner % 2 == 0 &&
+        hipMalloc((void **)&h->coef32, sizeof(float) * (size_t)(3 + h->P.nlig) * G.plane) != hipSuccess) { h->coef32 = nullptr; h->poly_fp32 = false; }
+    float *c32 = h->poly_fp32 ? h->coef32 : nullptr;
+    Scope sc(h, KC_GFIELD, (8.0 * (G.F + 3 + h->P.nlig) + (c32 ? 4.0 * (3 + h->P.nlig) : 0.0)) * (double)G.plane);
+    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef, c32));
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// Jacobian action from the frozen coefficients (see stencil.hip.h, "Frozen-Jacobian path")
+static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift, double *out,
+                         const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
+{
+    const KGeom &G = h->G;
+    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
+    if (fused_ok(h)) {
+        KStrips K = make_strips(h, true);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta));
+    } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
+        }
+        K3D K;
+        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+        K.nygrp = (int)((G.ny + 3) / 4);
+        K.zseg = h->zseg;
+        {
+            long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // blocks of 4 waves
+            if (fit < 2) fit = 2;
+            if (fit < K.zseg) K.zseg = (int)fit;
+        }
+        K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
+        long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
+        K.nblocks = (int)((nb3 + 7) / 8 * 8);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
+    } else {
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
+        }
+        int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
+        // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// Jacobian action with the halo exchange of v hidden behind the interior rows (slab ranks, 2-D fused kernel):
+//   compute stream: [interior segments]                      [two boundary segments]
+//   comm stream   :   wait(v ready) -> ghost rows of v <- ring neighbours -> signal
+// Interior segments read owned rows only; the first and last segment are the only readers of ghost rows.
+static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift, double *out,
+                              const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
+{
+    int rc;
+    const KGeom &G = h->G;
+    if (h->size == 1) return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
+    KStrips K = make_strips(h, true);
+    if (!h->overlap || !fused_ok(h) || K.nseg < 3 || h->P.nlig > 4) {
+        if ((rc = halo(h, v))) return rc;
+        return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
+    }
+    const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
+    const int nseg_total = K.nseg;
+    HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
+    {
+        KStrips Ki = K;
+        Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = nseg_total - 2;
+        long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
+        Ki.nblocks = (int)((nb + 7) / 8 * 8);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * (double)Ki.nseg / nseg_total);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Ki.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Ki, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
+    }
+    HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
+    {
+        Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * G.F * (double)G.inner * 2.0);
+        if (h->tr->exchange(v, G.F, G.plane, G.inner, G.sloc, G.ng, h->st_comm)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    }
+    HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
+    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
+    {
+        KStrips Kb = K;
+        Kb.seg0 = 0; Kb.seg_stride = nseg_total - 1; Kb.nseg = 2;
+        long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
+        Kb.nblocks = (int)((nb + 7) / 8 * 8);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * 2.0 / nseg_total);
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Kb.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Kb, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// The same strip kernel with mixed storage types (fp32 coefficient copy / Horner temporaries of the polynomial
+// preconditioner).  Same overlap scheme as op_jvp_frozen_halo; a float vector travels through the double-typed transport
+// as half as many doubles (inner and plane are even on this path).
+template <typename TC, typename TV, typename TY, typename TO>
+static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const TC *C, const TV *v, int mode, double shift,
+                          TO *out, const TY *yadd, double alpha, double beta)
+{
+    const KGeom &G = h->G;
+    const double per_pt = (3.0 + h->P.nlig) * sizeof(TC) + G.F * (double)(sizeof(TV) + sizeof(TO)) + ((mode == 2 || mode == 3) ? G.F * (double)sizeof(TY) : 0.0);
+    Scope sc(h, KC_JVP, per_pt * (double)G.nloc * frac);
+    NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, TC, TV, TY, TO>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st,
+                                                                     G, h->P, K, C, (const TV *)v, mode, shift, out, yadd, alpha, beta));
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+template <typename TC, typename TV, typename TY, typename TO>
+static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shift, TO *out, const TY *yadd, double alpha, double beta)
+{
+    const KGeom &G = h->G;
+    KStrips K = make_strips(h, true);
+    if (h->size == 1) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
+    const long long scale = sizeof(double) / sizeof(TV);            // 1 for double, 2 for float
+    const bool ovl = h->overlap && K.nseg >= 3;
+    int rc;
+    if (ovl) {
+        HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
+        KStrips Ki = K;
+        Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = K.nseg - 2;
+        long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
+        Ki.nblocks = (int)((nb + 7) / 8 * 8);
+        if ((rc = jvp2d_launch_t(h, Ki, (double)Ki.nseg / K.nseg, C, v, mode, shift, out, yadd, alpha, beta))) return rc;
+        HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
+    }
+    {
+        Scope sc(h, KC_HALO, 4.0 * 2.0 * sizeof(TV) * G.F * (double)G.inner * 2.0);
+        if (h->tr->exchange(reinterpret_cast<double *>(v), G.F, G.plane / scale, G.inner / scale, G.sloc, G.ng, ovl ? h->st_comm : h->st))
+            return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    }
+    if (!ovl) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
+    HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
+    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
+    KStrips Kb = K;
+    Kb.seg0 = 0; Kb.seg_stride = K.nseg - 1; Kb.nseg = 2;
+    long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
+    Kb.nblocks = (int)((nb + 7) / 8 * 8);
+    return jvp2d_launch_t(h, Kb, 2.0 / K.nseg, C, v, mode, shift, out, yadd, alpha, beta);
+}
+
+// VW = 2 when every plane/offset/length is even (all accesses 16-byte aligned double2)
+static inline bool vec2(const ksfd_handle *h) { return (h->G.nloc % 2 == 0) && (h->kv.off % 2 == 0) && (h->G.plane % 2 == 0); }
+static inline dim3 vgridw(const ksfd_handle *h, int vw) { return dim3((h->nblk_vec + vw - 1) / vw, h->G.F); }
+#define VW_DISPATCH(h, CALL) do { if (vec2(h)) { constexpr int VW = 2; CALL; } else { constexpr int VW = 1; CALL; } } while (0)
+
+static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const double *a, double *out)
+{
+    KLin L;
+    for (int t = 0; t < 6; t++) { L.x[t] = t < nt ? x[t] : nullptr; L.a[t] = t < nt ? a[t] : 0.0; }
+    Scope sc(h, KC_LINCOMB, vbytes(h, nt + 1));
+    switch (nt) {
+    case 1: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<1, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 2: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<2, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 3: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<3, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 4: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 5: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<5, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    default: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<6, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// d[0..k) = <w,V_i>, d[k] = <w,w>  -> h->hres
+static int op_multidot(ksfd_handle *h, const double *w, const double *V, int k)
+{
+    const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
+    {
+        Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
+        if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+    }
+    HIPCHK(h, hipGetLastError());
+    return reduce_rows(h, k + 1, nb, 0);
+}
+
+// d[0..k) = <w,V_i>, g[0..k) = <V_{k-1},V_i>, ww  -> h->hres[0..2k]
+static int op_multidot_gram(ksfd_handle *h, const double *w, const double *V, int k)
+{
+    const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
+    {
+        Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
+        if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<4, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<8, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<16, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+        else VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot_gram<32, VW>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, h->part));
+    }
+    HIPCHK(h, hipGetLastError());
+    return reduce_rows(h, 2 * k + 1, nb, 0);
+}
+
+static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const double *coef, double scale)
+{
+    KCoef C;
+    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
+    Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
+    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    else VW_DISPATCH(h, hipLaunchKernelGGL((k_gs_update<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, w, V, h->vlen, k, C, scale));
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta)
+{
+    KCoef C;
+    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
+    Scope sc(h, KC_BASISAXPY, vbytes(h, k + 1 + (beta != 0.0)));
+    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    else VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int op_copy(ksfd_handle *h, double *dst, const double *src)
+{
+    Scope sc(h, KC_MISC, vbytes(h, 2));
+    HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
+    return KSFD_OK;
+}
+
+// ---- host <-> device vectors -------------------------------------------------------------------
+static int upload(ksfd_handle *h, const double *host, int layout, double *dev)
+{
+    const KGeom &G = h->G;
+    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
+    HIPCHK(h, hipMemcpyAsync(h->flat, host, sizeof(double) * (size_t)G.F * G.nloc, hipMemcpyHostToDevice, h->st));
+    Scope sc(h, KC_MISC, vbytes(h, 2));
+    hipLaunchKernelGGL(k_from_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, h->flat, dev, G.plane,
+                       (long long)G.ng * G.inner);
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+static int download(ksfd_handle *h, const double *dev, int layout, double *host)
+{
+    const KGeom &G = h->G;
+    if (layout < 0 || layout > 2) return fail(h, KSFD_EINVAL, "bad layout %d", layout);
+    {
+        Scope sc(h, KC_MISC, vbytes(h, 2));
+        hipLaunchKernelGGL(k_to_host_layout, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, G, layout, dev, G.plane,
+                           (long long)G.ng * G.inner, h->flat);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(host, h->flat, sizeof(double) * (size_t)G.F * G.nloc, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    return KSFD_OK;
+}
