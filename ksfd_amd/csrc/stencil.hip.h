@@ -721,6 +721,9 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
 // except inside the polynomial preconditioner, whose Horner temporaries and coefficient copy are fp32).
 // PF = rows in flight ahead of the one being computed.  PF = 2 (fits for NL = 1: 226 VGPRs, still 2 waves/SIMD) was measured
 // and gains nothing: the kernel is co-limited by HBM and fp64/VALU issue (~2000 cycles per row and wave), not by latency.
+// Also measured and dropped: rotating the 5-row windows through a five-fold unrolled row loop (no register moves, same
+// 196 VGPR): 6 % SLOWER (0.198 -> 0.210 ms), the five copies of the body cost more in instruction fetch than the ~100
+// v_mov per row they save.
 template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double, int PF = 1>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const TC *__restrict__ C,
                                                              const TV *__restrict__ v, int mode, double shift,
