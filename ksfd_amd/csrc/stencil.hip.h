@@ -935,6 +935,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
         if (k + 1 < k1) load_plane(kmap(k + 3));
         const long long kc = kmap(k);
         const long long po = ksfd_planeoff(G, kc);
+        // the added vector of modes 2/3 is needed only at the store: issue its loads now (see k_jvp2d_frozen)
+        double2 yv_add[NL + 1];
+        if ((mode == 2 || mode == 3) && store) {
+            const long long oy = (long long)G.ng * G.inner + kc * G.nx * G.ny + rowc;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) yv_add[c] = ksfd_ld2(yadd + (long long)c * G.plane + oy);
+        }
         // y-neighbour rows of the centre plane
         double2 yr[4], yg[4], yv[4], ye[4];
 #pragma unroll
@@ -1002,7 +1009,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
                     const double c0 = c == 0 ? vw[2][0] : zw[c > 0 ? c - 1 : 0][2][0], c1 = c == 0 ? vw[2][1] : zw[c > 0 ? c - 1 : 0][2][1];
                     a = alpha * c0 + beta * a; b = alpha * c1 + beta * b;
                 } else if (mode >= 2) {
-                    const double2 yy = ksfd_ld2(yadd + (long long)c * G.plane + o);
+                    const double2 yy = yv_add[c];
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
