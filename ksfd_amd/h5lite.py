@@ -76,11 +76,11 @@ def _chk(x, what):
 
 def _np_and_type(val):
     a = np.asarray(val)
+    # np.array(..., order='C'), not np.ascontiguousarray: the latter turns a 0-d value into shape (1,), and the
+    # reference's reader tells scalars from arrays by np.isscalar (KSFD/ksfdtimeseries.py:264-291)
     if a.dtype.kind in 'iub':
-        a = np.ascontiguousarray(a, dtype=np.int64)
-        return a, lib().T_INT64
-    a = np.ascontiguousarray(a, dtype=np.float64)
-    return a, lib().T_DOUBLE
+        return np.array(a, dtype=np.int64, order='C'), lib().T_INT64
+    return np.array(a, dtype=np.float64, order='C'), lib().T_DOUBLE
 
 
 class File:

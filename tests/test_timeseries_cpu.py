@@ -58,3 +58,47 @@ print("h5py-ok")
 '''
     r = subprocess.run([CONDA_PY, '-c', code, ts.filename, str(tmp_path / 'want.npy')], capture_output=True, text=True)
     assert 'h5py-ok' in r.stdout, r.stderr
+
+
+REF_READER = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'read_series_with_reference.py')
+
+
+@pytest.mark.skipif(not (HAVE_H5 and os.path.exists(CONDA_PY) and os.path.isdir('/root/reference/KSFD')),
+                    reason='container-only: needs /root/reference and the conda h5py')
+@pytest.mark.parametrize('shape,nlig,size,rank', [((12, 10), 2, 1, 0), ((6, 5, 8), 1, 1, 0), ((14,), 1, 1, 0), ((12, 10), 1, 2, 1)])
+def test_series_file_opens_in_the_references_own_timeseries_reader(tmp_path, shape, nlig, size, rank):
+    """drop-in at the data-format boundary: KSFD.ksfdtimeseries.TimeSeries(prefix, mode='r') of the reference reads the
+    index, the grid description, every stored point and interpolates between two of them from a file this repo wrote"""
+    import subprocess
+    dim = len(shape)
+    cfg = ProblemConfig.standard(dim, shape, L=tuple(0.05 * n for n in shape), nlig=nlig)
+    nslow = shape[-1]
+    lo, hi = (rank * nslow // size, (rank + 1) * nslow // size)
+    grid = LocalGrid(cfg, (lo, hi), rank=rank, size=size)
+    prefix = str(tmp_path / 'ser' / 'run')
+    ts = TimeSeries(prefix, grid, mode='w')
+    assert ts.filename.endswith('s%dr%d.h5' % (size, rank))
+    rng = np.random.default_rng(4)
+    nloc = int(np.prod(grid.Vlshape))
+    stored, times = {}, [0.0, 0.5, 2.0, 1.25]                     # not monotone: /order must sort them
+    for k, t in enumerate(times):
+        a = rng.standard_normal(nloc)                               # local Vec, dof fastest (PETSc layout)
+        ts.store(a, t, k=k)
+        stored[k] = np.ascontiguousarray(a.reshape(grid.Vlshape, order='F'))
+    ts.set_dt(0.125)
+    ts.close()
+    out = str(tmp_path / 'seen.npz')
+    r = subprocess.run([CONDA_PY, REF_READER, prefix, out, str(size), str(rank)], capture_output=True, text=True, timeout=120)
+    assert 'reference-reader-ok' in r.stdout, r.stderr[-2000:]
+    z = np.load(out)
+    # (the reference's _sort() sorts its time array in place, ksfdtimeseries.py:375-387: times() comes back sorted)
+    assert np.array_equal(z['times'], sorted(times)) and list(z['steps']) == [0, 1, 2, 3]
+    assert np.array_equal(z['sorted_times'], sorted(times))
+    assert int(z['dim']) == dim and int(z['dof']) == nlig + 1
+    assert list(z['nps']) == list(shape) and np.allclose(z['bounds'], cfg.L[:dim])
+    for k in range(4):
+        assert np.array_equal(z['data%d' % k], stored[k])
+    tm = float(z['interp_t'])                                       # between t=0 (k=0) and t=0.5 (k=1)
+    want = ((tm - 0.0) * stored[1] + (0.5 - tm) * stored[0]) / 0.5
+    assert np.allclose(z['interp'], want, rtol=1e-14, atol=1e-15)
+    assert float(z['info_dt']) == 0.125
