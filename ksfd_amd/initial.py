@@ -9,8 +9,12 @@ which is O(hours) at 4096^2 and uses np.product, removed in numpy 2).
                f(x) + f(1-x) = 1, so every fine point is a convex combination of its 2^dim coarse neighbours
   rho = rho0 + noise ; U_gl = rho * s_gl / gamma_gl                          (ksfdsolver2.py:617-637)
 
-Parity note: the reference's random_function cannot be run here (it needs PETSc DMDA objects); this
-restatement is checked against oracle/ksfd_oracle.c:ko_random_function only -> "parity unpinned".
+Parity: pinned.  tests/golden/randfn_*.npz hold fields produced by the reference's own random_function (run in the
+build container on a data-only stand-in for its Grid, tests/golden/make_randfn_golden.py); this module, the oracle's
+ko_random_function and the device kernel (ksfd_set_state_random) reproduce them to 1e-14.  The reference flattens its
+coordinate arrays in C order but its Vecs in x-fastest order (ksfdrandom.py:183,193): on grids with the same point count
+on every axis -- all its shipped runs -- the two reversals cancel and the result is the tensor-product interpolation
+restated here; on other grids the reference returns a scramble of it, which is not reproduced.
 """
 import numpy as np
 

@@ -206,3 +206,17 @@ def test_device_start_values_vs_oracle_and_host_generator(shape, nlig, coarse):
     host = start_values(cfg, coarse=coarse)
     assert rel_l2(got, host) < 1e-14
     k.close()
+
+
+@pytest.mark.parametrize('name', golden_cases('randfn_'))
+def test_device_start_values_vs_reference_random_function(name):
+    """ksfd_set_state_random against the field the reference's KSFD.ksfdrandom.random_function produced from the same
+    coarse samples (tests/golden/randfn_*.npz)"""
+    z = load_golden(name)
+    n = tuple(int(x) for x in z['n'])
+    cfg = ProblemConfig.standard(len(n), n, L=tuple(float(x) for x in z['L']), nlig=1)
+    k = klib.KSFDHip(cfg)
+    k.set_state_random(z['z'] - 9000.0, rho0=9000.0)            # golden samples already carry the mean
+    rho = k.get_state()[:cfg.N].reshape(n, order='F')
+    assert np.abs(rho - z['out']).max() <= 1e-13 * np.abs(z['out']).max()
+    k.close()

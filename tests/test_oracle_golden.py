@@ -174,3 +174,17 @@ def test_oracle_adaptive_sequence_vs_reference_lu_golden(name):
         u, t, h = un, t + h, hn
     assert abs(t - z['t_acc'][-1]) <= 1e-9 * t
     assert rel_l2(u, cijk_to_soa(z['uN'])) < 1e-10
+
+
+@pytest.mark.parametrize('name', golden_cases('randfn_'))
+def test_start_value_interpolation_vs_reference_random_function(name):
+    """oracle (ko_random_function) and the host generator (ksfd_amd.initial) against the reference's own
+    KSFD.ksfdrandom.random_function, run by tests/golden/make_randfn_golden.py"""
+    from ksfd_amd.initial import smoothstep_interpolate
+    z = load_golden(name)
+    n, nc = tuple(int(x) for x in z['n']), tuple(int(x) for x in z['nc'])
+    cfg = ProblemConfig.standard(len(n), n, L=tuple(float(x) for x in z['L']), nlig=1)
+    got = ko.Oracle(cfg).random_function(list(nc) + [1] * (3 - len(n)), z['z'].ravel(order='F')).reshape(n, order='F')
+    scale = np.abs(z['out']).max()
+    assert np.abs(got - z['out']).max() <= 1e-14 * scale
+    assert np.abs(smoothstep_interpolate(z['z'], n) - z['out']).max() <= 1e-14 * scale
