@@ -88,3 +88,49 @@ def test_manufactured_initial_state_and_source_fields_match_golden():
     assert src[1].is_zero() and not src[0].is_zero()
     with pytest.raises(ValueError):
         ko_opts.decode_sources(['V=1'], ps)
+
+
+REF_DIR = '/root/reference'
+PARSED = os.path.join(GOLDEN, 'options_parsed.json')
+
+
+def _parsed_cases():
+    import json
+    return sorted(json.load(open(PARSED))) if os.path.exists(PARSED) else []
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DIR), reason='container-only: reads the reference\'s shipped options files')
+@pytest.mark.parametrize('fname', _parsed_cases())
+def test_shipped_options_files_parse_like_the_reference(fname):
+    """every options file the reference ships, through ksfd_amd.options, against the table the reference's own
+    parse_commandline + SolutionParameters produced for it (tests/golden/make_options_golden.py): all parameter values
+    (expressions compared at sample points), ligand / group tables, the --petsc pass-through block"""
+    import json
+    import sympy as sy
+    want = json.load(open(PARSED))[fname]
+    cl = ko_opts.parse_commandline(['@' + os.path.join(REF_DIR, fname)])
+    ps = ko_opts.Params(cl)
+    assert list(cl.petsc) == want['petsc']
+    assert cl.cappotential == want['cappotential'] and int(cl.seed) == want['seed'] and len(cl.source) == want['nsources']
+    assert cl.save == want['save'] and cl.check == want['check']
+    x, y, z, t = sy.symbols('x y z t')
+    samples = [(0.1, 0.2, 0.3, 0.0), (0.37, 0.11, 0.05, 1.5), (0.9, 0.45, 0.6, 40.0)]
+    mine = ps.values0
+    for key, ref in want['values0'].items():
+        assert key in mine, key
+        got = mine[key]
+        if isinstance(ref, dict):
+            e = sy.sympify(got)
+            vals = [float(e.subs({x: a, y: b, z: c, t: d})) for a, b, c, d in samples]
+            assert np.allclose(vals, ref['samples'], rtol=1e-13, atol=0), key
+        elif isinstance(ref, bool) or ref is None or isinstance(ref, str):
+            assert (got if isinstance(got, (bool, str)) or got is None else str(got)) == ref or (ref == '' and got in ('', None, False)), (key, got, ref)
+        else:
+            assert abs(float(got) - float(ref)) <= 1e-14 * abs(float(ref)), (key, got, ref)
+    cfg = ps.problem_config()
+    ligs, groups = want['ligands'], want['groups']
+    assert cfg.nlig == len(ligs) and cfg.ngroups == len(groups)
+    for l, (name, g, s, gamma, D, w) in enumerate(ligs):
+        assert int(cfg.lig_group[l]) == g - 1
+        assert np.allclose([cfg.lig_s[l], cfg.lig_gamma[l], cfg.lig_D[l], cfg.lig_w[l]], [s, gamma, D, w], rtol=1e-14, atol=0)
+    assert np.allclose(np.stack([cfg.grp_alpha, cfg.grp_beta], axis=1), groups, rtol=1e-14, atol=0)
