@@ -7,5 +7,9 @@ class _PETSc(_Any):
     class Vec: pass
     class Mat: pass
     class Comm: pass
+    class TS:
+        class Type: ROSW = 'rosw'
+        class ExactFinalTime: STEPOVER = 0
+    # ^ base class of KSFD.ksfdts.KSFDTS (tests/golden/make_noise_golden.py calls its plain-Python methods unbound)
 PETSc = _PETSc()
 def init(*a, **k): pass

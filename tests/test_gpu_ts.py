@@ -206,3 +206,33 @@ def test_snapshot_slots_hold_their_state_while_the_stepper_moves_on():
 def _to_hdf5(soa, cfg):
     F, (nx, ny) = cfg.F, cfg.n[:2]
     return np.ascontiguousarray(soa.reshape(F, ny, nx).transpose(0, 2, 1)).reshape(-1)     # (dof, x, y) C order
+
+
+def test_noise_injection_vs_the_references_own_methods():
+    """count_worms / add_variance / conserve_worms / is_noise_time of the mirror against tests/golden/noise_2d.npz, which the
+    reference's KSFDTS methods produced (tests/golden/make_noise_golden.py): same RNG stream, same fields"""
+    from ksfd_amd.ts import Derivatives, implicitTS
+    from ksfd_amd.initial import reference_rng
+    from ksfd_amd.layout import PETSC
+    z = load_golden('noise_2d')
+    nx, ny = (int(v) for v in z['n'])
+    ns = opt.parse_commandline(['dim=2', 'nwidth=%d' % nx, 'nheight=%d' % ny, 'width=0.3', 'height=0.24', 'ngroups=2',
+                                'nligands_1=1', 'nligands_2=1', 'alpha_1=1500', 'beta_1=5.56e-4', 's_1_1=0.01', 'gamma_1_1=0.01',
+                                'D_1_1=1e-6', 'alpha_2=1500', 'beta_2=-5.56e-4', 's_2_1=0.001', 'gamma_2_1=0.001', 'D_2_1=1e-5',
+                                'variance_rate=%r' % float(z['vrate']), 'variance_interval=%r' % float(z['interval']),
+                                'dt=0.004', 'maxsteps=1'])
+    ps = opt.Params(ns)
+    cfg = ps.problem_config()
+    assert cfg.F == int(z['F'])
+    d = Derivatives(ps, cfg)
+    d.ks.set_state(z['u0'], PETSC)
+    ts = implicitTS(d, t0=0.0, dt=0.004, tmax=1.0, maxsteps=1, rtol=1e-6, atol=0.01, rng=reference_rng(int(z['seed'])))
+    ts.setTime(float(z['t']))
+    N0 = ts.count_worms(ts.u)
+    assert abs(N0 - float(z['N0'])) <= 1e-13 * N0
+    ts.add_variance(ts.u, float(z['dt']))
+    assert rel_l2(d.ks.get_state(PETSC), z['u_var']) < 1e-15
+    ts.conserve_worms(ts.u, N0)
+    assert rel_l2(d.ks.get_state(PETSC), z['u_cons']) < 1e-14
+    assert [bool(ts.is_noise_time(a, b)) for a, b in z['times']] == [bool(f) for f in z['fire']]
+    ts.cleanup()
