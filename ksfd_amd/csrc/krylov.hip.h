@@ -188,6 +188,13 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     bool x_set = false;         // x holds an iterate (else it is taken as 0 and overwritten)
     bool restarted = false;
     const double *rsrc = b;
+    // x0 from the recycled spaces is not written on its own: its coefficients wait (indexed by absolute slot of Zb / V) and
+    // ride in the solution update of the first cycle -- one pass over x instead of two
+    const bool defer_x0 = rec_on && !use_pc;
+    std::vector<double> xcoef(KSFD_MAXDOT, 0.0);
+    bool x0_pending = false;
+    double *const Xbase = use_poly ? h->Zb : h->V;          // slot 0 of the basis the solution is expanded in
+    const int xslot0 = use_poly ? zb : vb;                  // first slot of this solve's own vectors
     if (rec_on && stage > 0) {
         static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
         for (int q = 0; q < stage; q++) {
@@ -205,8 +212,14 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
                 if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
                 else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
-            } else if ((rc = op_basis_axpy(h, x, Zs, S.k, yq, x_set ? 1.0 : 0.0))) return rc;
-            x_set = true;
+                x_set = true;
+            } else if (defer_x0) {
+                for (int i = 0; i < S.k; i++) xcoef[(use_poly ? S.zb : S.vb) + i] += yq[i];
+                x0_pending = true;
+            } else {
+                if ((rc = op_basis_axpy(h, x, Zs, S.k, yq, x_set ? 1.0 : 0.0))) return rc;
+                x_set = true;
+            }
             for (int i = 0; i <= S.k; i++) neg[i] = -Hy[i];
             if (rsrc == b) {
                 const double *xs[6] = { b }; double a[6] = { 1.0 };
@@ -215,14 +228,20 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 rsrc = h->t3;
             } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0))) return rc;
         }
-        if (x_set) {
+        if (x_set || x0_pending) {
             if ((rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
             beta = rn = sqrt(h->hres[0]);
             if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: projected residual is not finite");
         }
     }
     while (true) {
-        if (first && beta <= tol) break;                       // the recycled spaces already hold the solution
+        if (first && beta <= tol) {                            // the recycled spaces already hold the solution
+            if (x0_pending) {
+                if ((rc = op_basis_axpy(h, x, Xbase, xslot0, xcoef.data(), x_set ? 1.0 : 0.0))) return rc;
+                x0_pending = false; x_set = true;
+            }
+            break;
+        }
         // V0 = r / beta
         if (first) { const double *xs[1] = { rsrc }; double a[1] = { 1.0 / beta }; if ((rc = op_lincomb(h, 1, xs, a, V))) return rc; }
         else {
@@ -328,6 +347,10 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
             if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
             else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
+        } else if (x0_pending) {
+            for (int i = 0; i < j; i++) xcoef[xslot0 + i] = y[i];
+            if ((rc = op_basis_axpy(h, x, Xbase, xslot0 + j, xcoef.data(), x_set ? 1.0 : 0.0))) return rc;
+            x0_pending = false;
         } else if ((rc = op_basis_axpy(h, x, use_poly ? Zq : V, j, y.data(), x_set ? 1.0 : 0.0))) return rc;
         x_set = true;
         if (rec_on && first && !restarted && done && j >= 1) {

@@ -365,8 +365,9 @@ static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const
 static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta)
 {
     KCoef C;
-    for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
-    Scope sc(h, KC_BASISAXPY, vbytes(h, k + 1 + (beta != 0.0)));
+    int nread = 0;                                      // vectors with a zero coefficient are not loaded
+    for (int i = 0; i < KSFD_MAXDOT; i++) { C.h[i] = i < k ? coef[i] : 0.0; nread += C.h[i] != 0.0; }
+    Scope sc(h, KC_BASISAXPY, vbytes(h, nread + 1 + (beta != 0.0)));
     if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
     else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
     else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_basis_axpy(KVec g, double *__res
         }
 #pragma unroll
         for (int i = 0; i < KMAX; i++)
-            if (i < k) {
+            if (i < k && C.h[i] != 0.0) {                 // wave-uniform; a zero coefficient costs no load (slots of unused recycled spaces)
                 const typename KPack<VW>::T vv = kload<VW>(V + (long long)i * vstride + base + p);
 #pragma unroll
                 for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) + C.h[i] * kget(vv, e));
