@@ -166,7 +166,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
     const int64_t vs = h->vlen;
     bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen;
-    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 10) { if (stage != 0) rec_on = false; rec_reset(h); }
+    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 6) { if (stage != 0) rec_on = false; rec_reset(h); }
     const int vb = rec_on ? h->rec_vtop : 0, zb = rec_on ? h->rec_ztop : 0;
     const int m = std::min(m_opt, h->restart_alloc - vb);
     double *V = h->V + (int64_t)vb * vs;

@@ -111,7 +111,22 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     h->nblk_vec = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
     build_tableau(h);
 
+    // Krylov storage is what scales with the restart length: V (m+1 vectors) + Zb (m).  Size it to the HBM that is free:
+    // ~30 other full-size vectors (state, stage vectors, temporaries, coefficient planes, multigrid level 0 + coarse levels)
+    // must fit first.  m = 30 on anything up to ~12k^2 x 2 fields on a 288 GB MI355X; larger grids run with a shorter restart.
     h->restart_alloc = 30;
+    {
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree > 0) {
+            const double vecbytes = 8.0 * (double)h->vlen;
+            const double room = 0.92 * (double)mfree / vecbytes - 30.0;
+            const int fit = (int)floor((room - 1.0) / 2.0);
+            if (fit < 30) {
+                if (fit < 8) CFAIL(KSFD_ENOMEM, "grid too large for this device: %.1f GB free, a vector is %.2f GB, the solver needs ~47 of them", mfree / 1e9, vecbytes / 1e9);
+                h->restart_alloc = fit;
+            }
+        }
+    }
     double **vecs[] = { &h->u, &h->usave, &h->Z, &h->bvec, &h->t1, &h->t2, &h->t3, &h->errv };
     for (double **v : vecs) {
         if (alloc_d(h, v, h->vlen)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
@@ -145,7 +160,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         h->tr = make_transport(dist, G.F, G.inner, terr);
         if (!h->tr) CFAIL(KSFD_ECOMM, "transport %d: %s", dist->transport, terr.c_str());
     }
-    if (mg_build(h)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
+    if (mg_build(h)) { mg_free(h); h->mg_ok = false; }        // out of memory for the hierarchy: run without the multigrid preconditioner
     if (hipStreamSynchronize(h->st) != hipSuccess) CFAIL(KSFD_EHIP, "stream sync failed in create");
 #undef CFAIL
     *out = h;

@@ -269,3 +269,23 @@ def test_krylov_recycling_across_stages_saves_iterations_same_answer():
         assert rel_l2(res[name, 1e-11][1], un) < 1e-10, name
         assert rel_l2(res[name, 1e-6][1], un) < 1e-7, name
     k.close()
+
+
+@pytest.mark.parametrize('restart', [5, 9])
+def test_short_restart_lengths_give_the_same_step(restart):
+    """large grids run with a restart length sized to the free HBM (ksfd_create); restarts + recycling with few slots must
+    not change the answer"""
+    n = 48
+    cfg = ProblemConfig.standard(2, (n, n), L=(n * 4.0 / 1536, n * 4.0 / 1536), nlig=1)
+    rng = np.random.default_rng(23)
+    rho = 9000 + 90 * rng.standard_normal(n * n)
+    u = np.concatenate([rho, rho])
+    h = 0.05
+    un, _, _, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=1e-13, maxit=4000)
+    k = klib.KSFDHip(cfg)
+    for pc in (0, 2):
+        k.set_state(u)
+        t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, ksp_restart=restart,
+                                                              ksp_max_it=4000, pc_type=pc))
+        assert rel_l2(k.get_state(), un) < 1e-9, (pc, st.linear_its)
+    k.close()
