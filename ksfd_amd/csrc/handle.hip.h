@@ -68,7 +68,7 @@ struct ksfd_handle {
 
     // tuning
     int use_fused = 1;
-    int yseg = 35;        // rows per wave segment, RHS kernel (measured best at 4096^2)
+    int yseg = 20;        // rows per wave segment, RHS kernel (tools/yseg_sweep.py at 4096^2: 0.284 ms vs 0.305 at 32+)
     int yseg_jvp = 16;    // same for the Jacobian-action kernels
     int zseg = 32;        // planes per wave segment, 3-D z-marching kernel
 
