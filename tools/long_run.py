@@ -13,6 +13,9 @@ ks = klib.KSFDHip(cfg)
 ks.set_state(start_values(cfg))
 if len(sys.argv) > 4:
     ks.set_mg_params(nu=int(sys.argv[4]))
+import os
+if os.environ.get('KSFD_TUNE'):
+    ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
 opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
 t, h = 0.0, 1e-8
 T0 = time.perf_counter()
