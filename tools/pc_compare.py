@@ -9,6 +9,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = build_problem(n, 1)
 u0 = start_values(cfg)
 ks = klib.KSFDHip(cfg)
+import os
+if os.environ.get('KSFD_MG'):                      # nu,ncoarse_max,ratio,coarse_tol
+    a = os.environ['KSFD_MG'].split(',')
+    ks.set_mg_params(nu=int(a[0]), ncoarse_max=int(a[1]), ratio=float(a[2]), coarse_tol=float(a[3]))
 for h in (0.02, 0.05, 0.1, 0.2, 0.5, 1.0):
     for name, pc, deg, tgt in (('mg', 1, 3, 0.02), ('poly3', 3, 3, 0.02), ('poly6', 3, 6, 0.02), ('poly6t', 3, 6, 0.1), ('poly4t', 3, 4, 0.1)):
         ks.set_poly_params(deg, tgt)
