@@ -202,6 +202,7 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * bit10 set = form the stage vectors with separate passes instead of inside the RHS kernel;
  * bit11 set = fetch reduction results with a stream synchronisation + copy instead of spinning on a flag the
  * reduction kernel raises in mapped host memory;
+ * bit12 set = multigrid smoother as separate kernels instead of inside the Jacobian-action epilogues;
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

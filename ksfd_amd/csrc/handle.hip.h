@@ -119,6 +119,7 @@ struct ksfd_handle {
 
     // multigrid preconditioner
     std::vector<MGLevel> mg;
+    bool mg_fuse = true;         // smoother algebra inside the Jacobian-action epilogues (modes 5/6)
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
     double mg_shift = -1.0;      // shift the block diagonals / eigen-bounds were built for
     bool mg_coef_valid = false;  // coarse coefficient planes match the current frozen state

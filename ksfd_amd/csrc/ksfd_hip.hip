@@ -738,6 +738,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->poly_fp32 = !(use_fused & 512);
         h->fuse_stage = !(use_fused & 1024);
         h->zero_copy = !(use_fused & 2048) && h->hres_dev;
+        if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;
     if (yseg_jvp > 0) h->yseg_jvp = yseg_jvp;

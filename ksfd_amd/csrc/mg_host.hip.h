@@ -88,12 +88,23 @@ static int mg_halo(ksfd_handle *h, MGLevel &L, double *v, int np)
 }
 
 // out = J v | shift v - J v | yadd - (shift v - J v) on level L
-static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double shift, double *out, const double *yadd)
+// sm != NULL: modes 5 / 6, smoother algebra in the epilogue (2-D strip kernel and generic kernel only: see mg_can_fuse)
+static bool mg_can_fuse(const ksfd_handle *h, const MGLevel &L)
+{
+    const KGeom &G = L.G;
+    const bool strip3d = G.dim == 3 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4;
+    return h->mg_fuse && !strip3d;
+}
+
+static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double shift, double *out, const double *yadd,
+                 const KSmooth *sm = nullptr)
 {
     const KGeom &G = L.G;
     if (h->size > 1) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
     const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
-    const double by = 8.0 * ((3 + h->P.nlig) + 2.0 * G.F + (mode == 2 ? G.F : 0)) * (double)G.nloc;
+    // planes moved: coefficients + v, plus per mode: 1/2: out (+ yadd); 5: yadd, Dinv, r, d; 6: Dinv, rr, x in and out
+    const double by = 8.0 * ((3 + h->P.nlig) + G.F + (mode == 5 ? 3.0 * G.F + G.F * G.F : mode == 6 ? 3.0 * G.F + G.F * G.F : G.F + (mode == 2 ? G.F : 0))) * (double)G.nloc;
+    const KSmooth S = sm ? *sm : KSmooth{};
     if (G.dim == 2 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
         KStrips K;
         K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
@@ -108,6 +119,9 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
         long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
         K.nblocks = (int)((nb + 7) / 8 * 8);
         Scope sc(h, cls, by);
+        if (sm) {
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, double, double, double, double, 1, true>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd, 0.0, 0.0, S));
+        } else
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd));
     } else if (G.dim == 3 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
@@ -130,7 +144,7 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         Scope sc(h, cls, by + 8.0 * G.plane);
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)L.coef, v, L.dG));
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, L.P, (const double *)L.coef, v, (const double *)(L.coef + G.plane), (const double *)L.dG, mode, shift, out, yadd));
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, L.P, (const double *)L.coef, v, (const double *)(L.coef + G.plane), (const double *)L.dG, mode, shift, out, yadd, 0.0, 0.0, S));
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -227,6 +241,25 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
     const double lmax = L.lam_max, lmin = lmax / ratio;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig1 = theta / delta;
     const long long off = L.kv.off;     // owned rows start here inside a (ghosted) plane
+    if (nu == 2 && mg_can_fuse(h, L)) {
+        // the default V(2,2) sweeps with the smoother algebra in the Jacobian-action epilogues: 2 launches instead of 3 (zero guess)
+        // or 4 (correction), and the residual / A d round trips through memory disappear (modes 5 and 6, KSmooth)
+        const double rho0 = 1.0 / sig1, rhon = 1.0 / (2.0 * sig1 - rho0);
+        KSmooth S = KSmooth{};
+        S.dinv = L.dinv; S.x = x; S.c1 = rhon * rho0; S.c2 = 2.0 * rhon / delta;
+        if (zero_init) {
+            {
+                Scope sc(h, KC_MG, 8.0 * (3 * F + F * F) * L.G.nloc);
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), b + off, 1.0 / theta, L.d + off, x + off));
+            }
+            S.rr = b; S.x_has_d = 1;
+            return mg_op(h, L, L.d, 6, shift, nullptr, nullptr, &S);
+        }
+        S.out2 = L.d; S.scale = 1.0 / theta;
+        if ((rc = mg_op(h, L, x, 5, shift, L.r, b, &S))) return rc;
+        S.rr = L.r; S.x_has_d = 0;
+        return mg_op(h, L, L.d, 6, shift, nullptr, nullptr, &S);
+    }
     const double *res = b;
     if (!zero_init) {
         if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;        // r = b - A x

@@ -26,6 +26,17 @@ struct KComb {
     double ain[3], aout[3];
 };
 
+// Smoother algebra of the multigrid preconditioner folded into the Jacobian-action epilogue (modes 5 and 6):
+//   5:  r = yadd - A v  -> out ;  d = scale * Dinv r -> out2                (residual + first Chebyshev direction)
+//   6:  x += (x_has_d ? 0 : d) + c1*d + c2 * Dinv (rr - A d),  v = d        (k_cheb_last without the A d round trip)
+// Dinv: F*F planes of the inverse point-block diagonal (row-major), all vectors in the level's ghosted layout.
+struct KSmooth {
+    const double *dinv, *rr;
+    double *x, *out2;
+    double c1, c2, scale;
+    int x_has_d;
+};
+
 // ---------------------------------------------------------------------------------------------
 // generic family
 // ---------------------------------------------------------------------------------------------
@@ -148,9 +159,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
                                                             const double *__restrict__ Gb,
                                                             const double *__restrict__ dGb, int mode, double shift,
                                                             double *__restrict__ out, const double *__restrict__ yadd = nullptr,
-                                                            double alpha = 0.0, double beta = 0.0)
+                                                            double alpha = 0.0, double beta = 0.0, KSmooth sm = KSmooth{})
 {
     // mode 0: J v | 1: shift v - J v | 2: yadd - (shift v - J v) | 3: alpha*yadd + beta*(shift v - J v)
+    // 5 / 6: smoother algebra of the multigrid preconditioner in the epilogue (KSmooth)
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < G.nloc; p += stride) {
         long long i, j, k;
@@ -181,6 +193,27 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
         }
         const long long o = (long long)G.ng * G.inner + p;
         double jr = acc + v0 * lapG + rho0 * lapdG;
+        if (mode >= 5) {
+            double q[NL + 1], dc[NL + 1];
+            q[0] = shift * v0 - jr; dc[0] = v0;
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const double ju = -P.lig_gamma[l] * V0[l] + P.lig_s[l] * v0 + P.lig_D[l] * lapV[l];
+                q[l + 1] = shift * V0[l] - ju; dc[l + 1] = V0[l];
+            }
+#pragma unroll
+            for (int c = 0; c <= NL; c++) q[c] = (mode == 5 ? yadd[(long long)c * G.plane + o] : sm.rr[(long long)c * G.plane + o]) - q[c];
+#pragma unroll
+            for (int a = 0; a <= NL; a++) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c <= NL; c++) s += sm.dinv[(long long)(a * (NL + 1) + c) * G.plane + o] * q[c];
+                const long long oa = (long long)a * G.plane + o;
+                if (mode == 5) { out[oa] = q[a]; sm.out2[oa] = sm.scale * s; }
+                else sm.x[oa] += (sm.x_has_d ? 0.0 : dc[a]) + sm.c1 * dc[a] + sm.c2 * s;
+            }
+            continue;
+        }
         double o0 = mode ? shift * v0 - jr : jr;
         if (mode == 2) o0 = yadd[o] - o0;
         else if (mode == 3) o0 = alpha * yadd[o] + beta * o0;
@@ -724,11 +757,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
 // Also measured and dropped: rotating the 5-row windows through a five-fold unrolled row loop (no register moves, same
 // 196 VGPR): 6 % SLOWER (0.198 -> 0.210 ms), the five copies of the body cost more in instruction fetch than the ~100
 // v_mov per row they save.
-template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double, int PF = 1>
+template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double, int PF = 1, bool SMOOTH = false>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const TC *__restrict__ C,
                                                              const TV *__restrict__ v, int mode, double shift,
                                                              TO *__restrict__ out, const TY *__restrict__ yadd = nullptr,
-                                                             double alpha = 0.0, double beta = 0.0)
+                                                             double alpha = 0.0, double beta = 0.0, KSmooth sm = KSmooth{})
 {
     // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x) ;
     // 3: out = alpha*yadd + beta*(shift*v - J v)   (one Horner step of the polynomial preconditioner) ;
@@ -782,10 +815,25 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         if (r + PF < J.r1) load_row(Bc, J.row(r + 2 + PF));
         // the added vector of modes 2/3 is needed only at the store: issue its loads now, behind the next row's
         double2 yv[NL + 1];
-        if ((mode == 2 || mode == 3) && J.store) {
+        if ((mode == 2 || mode == 3 || (SMOOTH && mode == 5)) && J.store) {
             const long long oy = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
 #pragma unroll
             for (int c = 0; c <= NL; c++) yv[c] = ksfd_ld2(yadd + (long long)c * G.plane + oy);
+        }
+        double2 dv_[SMOOTH ? (NL + 1) * (NL + 1) : 1], xs_[SMOOTH ? NL + 1 : 1], rs_[SMOOTH ? NL + 1 : 1];
+        if constexpr (SMOOTH) {
+            if (mode >= 5 && J.store) {
+                const long long oy = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
+#pragma unroll
+                for (int q = 0; q < (NL + 1) * (NL + 1); q++) dv_[q] = ksfd_ld2(sm.dinv + (long long)q * G.plane + oy);
+                if (mode == 6) {
+#pragma unroll
+                    for (int c = 0; c <= NL; c++) {
+                        xs_[c] = ksfd_ld2(sm.x + (long long)c * G.plane + oy);
+                        rs_[c] = ksfd_ld2(sm.rr + (long long)c * G.plane + oy);
+                    }
+                }
+            }
         }
         const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
         const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
@@ -825,7 +873,33 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                 res[l + 1][e] = mode ? shift * zw[l][2][e] - ju : ju;
             }
         }
-        if (J.store) {
+        if (SMOOTH && mode >= 5) {
+            if constexpr (SMOOTH) {
+                if (J.store) {
+                    const long long o = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
+                    double q0[NL + 1], q1[NL + 1];                    // mode 5: r = yadd - A v ; mode 6: rr - A d
+#pragma unroll
+                    for (int c = 0; c <= NL; c++) {
+                        q0[c] = (mode == 5 ? yv[c].x : rs_[c].x) - res[c][0];
+                        q1[c] = (mode == 5 ? yv[c].y : rs_[c].y) - res[c][1];
+                    }
+#pragma unroll
+                    for (int a = 0; a <= NL; a++) {
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int c = 0; c <= NL; c++) { s0 += dv_[a * (NL + 1) + c].x * q0[c]; s1 += dv_[a * (NL + 1) + c].y * q1[c]; }
+                        if (mode == 5) {
+                            ksfd_st2(out + (long long)a * G.plane + o, q0[a], q1[a]);
+                            ksfd_st2(sm.out2 + (long long)a * G.plane + o, sm.scale * s0, sm.scale * s1);
+                        } else {
+                            const double d0 = a == 0 ? vw[2][0] : zw[a > 0 ? a - 1 : 0][2][0], d1 = a == 0 ? vw[2][1] : zw[a > 0 ? a - 1 : 0][2][1];
+                            ksfd_st2(sm.x + (long long)a * G.plane + o, xs_[a].x + (sm.x_has_d ? 0.0 : d0) + sm.c1 * d0 + sm.c2 * s0,
+                                     xs_[a].y + (sm.x_has_d ? 0.0 : d1) + sm.c1 * d1 + sm.c2 * s1);
+                        }
+                    }
+                }
+            }
+        } else if (J.store) {
             const long long o = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
 #pragma unroll
             for (int c = 0; c <= NL; c++) {

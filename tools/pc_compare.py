@@ -10,6 +10,8 @@ cfg = build_problem(n, 1)
 u0 = start_values(cfg)
 ks = klib.KSFDHip(cfg)
 import os
+if os.environ.get('KSFD_TUNE'):
+    ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
 if os.environ.get('KSFD_MG'):                      # nu,ncoarse_max,ratio,coarse_tol
     a = os.environ['KSFD_MG'].split(',')
     ks.set_mg_params(nu=int(a[0]), ncoarse_max=int(a[1]), ratio=float(a[2]), coarse_tol=float(a[3]))
