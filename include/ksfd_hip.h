@@ -210,7 +210,7 @@ int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t
 int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t power_its, double ratio, double coarse_tol);
 /* Chebyshev polynomial preconditioner: highest degree (default 6, at most 7; 0 = off), the residual reduction per
  * outer iteration that picks the degree (default 0.02; <= 0 keeps), and the stiffness h*gamma*lambda_max(diffusion)
- * above which pc_type 2 hands over to multigrid (default 60; <= 0 keeps) */
+ * above which pc_type 2 hands over to multigrid (default 75; <= 0 keeps) */
 int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target, double mg_threshold);
 
 #ifdef __cplusplus

@@ -96,7 +96,7 @@ struct ksfd_handle {
     double poly_alpha[8];           // z = sum_i alpha_i (A/shift)^i v
     double poly_shift = -1.0;
     int poly_max_deg = 6;
-    double mg_threshold = 60.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
+    double mg_threshold = 75.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
     float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
     bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path)
