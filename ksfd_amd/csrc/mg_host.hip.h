@@ -118,9 +118,15 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
         K.seg0 = 0; K.seg_stride = 1;
         long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
         K.nblocks = (int)((nb + 7) / 8 * 8);
-        Scope sc(h, cls, by);
-        if (sm) {
+        // level 0 reads the fp32 copy of the coefficient planes when there is one (the V cycle is a preconditioner: see poly_apply)
+        const float *c32 = (&L == &h->mg[0] && h->poly_fp32) ? h->coef32 : nullptr;
+        Scope sc(h, cls, by - (c32 ? 4.0 * (3 + h->P.nlig) * (double)G.nloc : 0.0));
+        if (sm && c32) {
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, float, double, double, double, 1, true>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, c32, v, mode, shift, out, yadd, 0.0, 0.0, S));
+        } else if (sm) {
             NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, double, double, double, double, 1, true>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd, 0.0, 0.0, S));
+        } else if (c32) {
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, float, double, double, double>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, c32, v, mode, shift, out, yadd));
         } else
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd));
     } else if (G.dim == 3 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
