@@ -22,7 +22,7 @@ struct MGLevel {
     int64_t vlen = 0;
     int nblk = 1;
     double *coef = nullptr;    // [rho, G, G_rho, G_U..] planes (level 0 aliases the handle's)
-    double *dinv = nullptr;    // F*F planes
+    float *dinv = nullptr;     // F*F planes (fp32)
     double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *Ad = nullptr, *dG = nullptr;
     double lam_max = 2.3;
     double ratio = 60.0;       // lambda_max/lambda_min estimate (used on the coarsest grid)

@@ -105,12 +105,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add3d(int nplanes, long 
     }
 }
 
-// Inverse of the point-block diagonal of A = shift*I - J (F x F per point, row-major planes dinv[(r*F+c)*plane]):
+// Inverse of the point-block diagonal of A = shift*I - J (F x F per point, row-major planes dinv[(r*F+c)*plane], stored in
+// fp32: it only scales the smoother of a preconditioner, and it is read three times per smoothing sweep):
 //   D_rr = shift - (lapG + rho*G_rho*c2),  D_rUl = -rho*G_Ul*c2,  D_Ulr = -s_l,  D_UlUl = shift + gamma_l - D_l*c2
 // with c2 = sum_a (-30/12)/h_a^2 the centre weight of the 4th-order Laplacian.
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, const double *__restrict__ C, double shift,
-                                                              double *__restrict__ dinv)
+                                                              float *__restrict__ dinv)
 {
     constexpr int F = NL + 1;
     const double *Gb = C + G.plane;
@@ -156,13 +157,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, 
 #pragma unroll
         for (int r = 0; r < F; r++)
 #pragma unroll
-            for (int c = 0; c < F; c++) dinv[(long long)(r * F + c) * G.plane + o] = Inv[r][c];
+            for (int c = 0; c < F; c++) dinv[(long long)(r * F + c) * G.plane + o] = (float)Inv[r][c];
     }
 }
 
 // z = scale * Dinv r   (and z2 = the same values when z2 != NULL: first Chebyshev sweep from a zero guess, x = d)
 template <int NL>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long long plane, const double *__restrict__ dinv,
+__global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long long plane, const float *__restrict__ dinv,
                                                            const double *__restrict__ r, double scale, double *__restrict__ z,
                                                            double *__restrict__ z2 = nullptr)
 {
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long lon
 
 // Last Chebyshev sweep: x += d_old + d_new with d_new = c1*d_old + c2*Dinv (r - Ad); r and d are dead afterwards.
 template <int NL>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_last(long long n, long long plane, const double *__restrict__ dinv,
+__global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_last(long long n, long long plane, const float *__restrict__ dinv,
                                                           double *__restrict__ x, const double *__restrict__ r,
                                                           const double *__restrict__ d, const double *__restrict__ Ad,
                                                           double c1, double c2, int x_has_d)
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_last(long long n, long long
 // One Chebyshev recurrence step after Ad = A d is known:
 //   x += d ; r -= Ad ; d = c1*d + c2*(Dinv r)
 template <int NL>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_step(long long n, long long plane, const double *__restrict__ dinv,
+__global__ void __launch_bounds__(KSFD_BLOCK) k_cheb_step(long long n, long long plane, const float *__restrict__ dinv,
                                                           double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
                                                           const double *__restrict__ Ad, double c1, double c2)
 {
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_hash_fill(long long n, double *_
 
 // per-block max over points of 1/(shift * [Dinv]_00): ~ largest diagonal-to-shift ratio, i.e. an estimate of
 // lambda_max/lambda_min of Dinv*A on a grid whose smoothest modes see only the shift
-__global__ void __launch_bounds__(KSFD_BLOCK) k_ratio_est(long long n, const double *__restrict__ dinv00, double shift,
+__global__ void __launch_bounds__(KSFD_BLOCK) k_ratio_est(long long n, const float *__restrict__ dinv00, double shift,
                                                           double *__restrict__ part)
 {
     __shared__ double red[KSFD_BLOCK / KSFD_WAVE];

@@ -10,7 +10,8 @@ static void mg_free(ksfd_handle *h)
     if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
     for (size_t l = 0; l < h->mg.size(); l++) {
         MGLevel &L = h->mg[l];
-        double *bufs[] = { l ? L.coef : nullptr, L.dinv, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG };
+        if (L.dinv) hipFree(L.dinv);
+        double *bufs[] = { l ? L.coef : nullptr, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG };
         for (double *b : bufs) if (b) hipFree(b);
     }
     h->mg.clear();
@@ -38,7 +39,7 @@ static int mg_build(ksfd_handle *h)
         L.nblk = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 2048);
         if (l == 0) L.coef = h->coef;
         else if (alloc_d(h, &L.coef, (int64_t)(3 + nl) * L.G.plane) || alloc_d(h, &L.x, L.vlen) || alloc_d(h, &L.b, L.vlen)) return KSFD_ENOMEM;
-        if (alloc_d(h, &L.dinv, (int64_t)F * F * L.G.plane) || alloc_d(h, &L.r, L.vlen) || alloc_d(h, &L.d, L.vlen) ||
+        if (hipMalloc((void **)&L.dinv, sizeof(float) * (size_t)F * F * L.G.plane) != hipSuccess || alloc_d(h, &L.r, L.vlen) || alloc_d(h, &L.d, L.vlen) ||
             alloc_d(h, &L.Ad, L.vlen) || alloc_d(h, &L.dG, L.G.plane)) return KSFD_ENOMEM;
         double *zero[] = { l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad };
         for (double *z : zero) if (z) hipMemsetAsync(z, 0, sizeof(double) * (size_t)L.vlen, h->st);
@@ -103,7 +104,7 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
     if (h->size > 1) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
     const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
     // planes moved: coefficients + v, plus per mode: 1/2: out (+ yadd); 5: yadd, Dinv, r, d; 6: Dinv, rr, x in and out
-    const double by = 8.0 * ((3 + h->P.nlig) + G.F + (mode == 5 ? 3.0 * G.F + G.F * G.F : mode == 6 ? 3.0 * G.F + G.F * G.F : G.F + (mode == 2 ? G.F : 0))) * (double)G.nloc;
+    const double by = 8.0 * ((3 + h->P.nlig) + G.F + (mode == 5 ? 3.0 * G.F + 0.5 * G.F * G.F : mode == 6 ? 3.0 * G.F + 0.5 * G.F * G.F : G.F + (mode == 2 ? G.F : 0))) * (double)G.nloc;
     const KSmooth S = sm ? *sm : KSmooth{};
     if (G.dim == 2 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
         KStrips K;
@@ -211,7 +212,7 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
             if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
             {
                 Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
-                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0, L.r + L.kv.off));
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0, L.r + L.kv.off));
             }
             double nw;
             if ((rc = mg_norm(h, L, L.r, &nw))) return rc;
@@ -219,13 +220,13 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
             lam = nw / nv;
             // v <- w / |w|
             Scope sc(h, KC_MG, 16.0 * L.vlen);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0 / nw, L.d + L.kv.off));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0 / nw, L.d + L.kv.off));
             nv = 1.0;
         }
         L.lam_max = 1.15 * lam;
         if (l + 1 == h->mg.size()) {
             int nbr = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 256);
-            hipLaunchKernelGGL(k_ratio_est, dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, (long long)L.G.nloc, (const double *)(L.dinv + L.kv.off), shift, h->part);
+            hipLaunchKernelGGL(k_ratio_est, dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, (long long)L.G.nloc, (const float *)(L.dinv + L.kv.off), shift, h->part);
             if ((rc = reduce_rows(h, 1, nbr, 1))) return rc;
             L.ratio = std::max(30.0, 1.5 * L.lam_max * h->hres[0]);
         }
@@ -255,8 +256,8 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
         S.dinv = L.dinv; S.x = x; S.c1 = rhon * rho0; S.c2 = 2.0 * rhon / delta;
         if (zero_init) {
             {
-                Scope sc(h, KC_MG, 8.0 * (3 * F + F * F) * L.G.nloc);
-                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), b + off, 1.0 / theta, L.d + off, x + off));
+                Scope sc(h, KC_MG, 8.0 * (3 * F + 0.5 * F * F) * L.G.nloc);
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), b + off, 1.0 / theta, L.d + off, x + off));
             }
             S.rr = b; S.x_has_d = 1;
             return mg_op(h, L, L.d, 6, shift, nullptr, nullptr, &S);
@@ -272,8 +273,8 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
         res = L.r;
     }
     {
-        Scope sc(h, KC_MG, 8.0 * ((zero_init ? 3 : 2) * F + F * F) * L.G.nloc);
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), res + off, 1.0 / theta, L.d + off, zero_init ? x + off : (double *)nullptr));
+        Scope sc(h, KC_MG, 8.0 * ((zero_init ? 3 : 2) * F + 0.5 * F * F) * L.G.nloc);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), res + off, 1.0 / theta, L.d + off, zero_init ? x + off : (double *)nullptr));
     }
     bool x_has_d = zero_init;          // x == d_0 already
     double rho = 1.0 / sig1;
@@ -282,16 +283,16 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
         const double rhon = 1.0 / (2.0 * sig1 - rho);
         const double *rsrc = (zero_init && k == 1) ? b : L.r;             // first sweep from a zero guess: r_0 = b, never copied
         if (k == nu - 1) {
-            Scope sc(h, KC_MG, 8.0 * (5 * F + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_last<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), x + off, rsrc + off, (const double *)(L.d + off), (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta, x_has_d ? 1 : 0));
+            Scope sc(h, KC_MG, 8.0 * (5 * F + 0.5 * F * F) * L.G.nloc);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_last<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), x + off, rsrc + off, (const double *)(L.d + off), (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta, x_has_d ? 1 : 0));
             x_has_d = true;
         } else {
             if (rsrc != L.r) HIPCHK(h, hipMemcpyAsync(L.r, b, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
             if (x_has_d && k == 1) { /* x already holds d_0: the step kernel adds d to x, so undo by starting x at 0 */
                 HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)L.vlen, h->st));
             }
-            Scope sc(h, KC_MG, 8.0 * (7 * F + F * F) * L.G.nloc);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const double *)(L.dinv + off), x + off, L.r + off, L.d + off, (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta));
+            Scope sc(h, KC_MG, 8.0 * (7 * F + 0.5 * F * F) * L.G.nloc);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_cheb_step<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), x + off, L.r + off, L.d + off, (const double *)(L.Ad + off), rhon * rho, 2.0 * rhon / delta));
             x_has_d = false;
         }
         rho = rhon;

@@ -31,7 +31,8 @@ struct KComb {
 //   6:  x += (x_has_d ? 0 : d) + c1*d + c2 * Dinv (rr - A d),  v = d        (k_cheb_last without the A d round trip)
 // Dinv: F*F planes of the inverse point-block diagonal (row-major), all vectors in the level's ghosted layout.
 struct KSmooth {
-    const double *dinv, *rr;
+    const float *dinv;
+    const double *rr;
     double *x, *out2;
     double c1, c2, scale;
     int x_has_d;
