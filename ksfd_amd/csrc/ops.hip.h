@@ -33,7 +33,10 @@ static int spin_for(ksfd_handle *h, unsigned long long seq)
 
 static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
 {
-    const bool zc = h->zero_copy && !h->capturing && rows <= 128;
+    // (single rank only for now: the RCCL variant -- k_publish after the all-reduce -- has never run on real multi-GPU hardware,
+    //  KSFD_ZC_MULTI=1 enables it)
+    static const bool zc_multi = getenv("KSFD_ZC_MULTI") != nullptr;
+    const bool zc = h->zero_copy && !h->capturing && rows <= 128 && (h->size == 1 || zc_multi);
     const bool zc_here = zc && h->size == 1;
     const unsigned long long seq = zc ? ++h->pub_seq : 0;
     {
