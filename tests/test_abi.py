@@ -43,3 +43,39 @@ def test_no_gpu_fails_loudly():
     from ksfd_amd.config import ProblemConfig
     with pytest.raises(klib.KSFDError):
         klib.KSFDHip(ProblemConfig.standard(2, (16, 16)))
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """the boundary is a C ABI: include/ksfd_hip.h must compile as pedantic C99, and a C program linked against
+    libksfd_hip.so must be able to call it (no compute without a GPU: defaults, names, the error path of ksfd_create)"""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    if not os.path.exists(klib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    inc = os.path.join(ROOT, 'include')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-x', 'c', os.path.join(inc, 'ksfd_hip.h')], check=True)
+    src = tmp_path / 'use_abi.c'
+    src.write_text('''
+#include "ksfd_hip.h"
+#include <stdio.h>
+int main(void) {
+    ksfd_step_opts o;
+    ksfd_config c = {0};
+    ksfd_handle *h = 0;
+    int rc;
+    ksfd_default_step_opts(&o);
+    printf("class1=%s rtol=%g pc=%d\\n", ksfd_kernel_class_name(1), o.ksp_rtol, (int)o.pc_type);
+    rc = ksfd_create(&c, 0, &h);                 /* dim = 0: rejected before any device is touched */
+    printf("rc=%d err=%s\\n", rc, ksfd_last_error(0));
+    return rc == 0;
+}
+''')
+    exe = tmp_path / 'use_abi'
+    libdir = os.path.dirname(klib.LIB_PATH)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-I', inc, str(src), '-o', str(exe), '-L', libdir, '-lksfd_hip', '-Wl,-rpath,' + libdir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert 'class1=jvp rtol=1e-06 pc=2' in r.stdout and 'rc=1' in r.stdout and 'dim must be' in r.stdout
