@@ -175,8 +175,23 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     double *Zq = use_poly ? h->Zb + (int64_t)zb * vs : nullptr;
     int rc;
     std::vector<double> H((size_t)(m + 1) * m, 0.0), Hraw((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2), d(m + 2), Gm((size_t)(m + 1) * (m + 1), 0.0);
-    if ((rc = op_multidot(h, b, V, 0))) return rc;
-    const double bn = sqrt(h->hres[0]);
+    // ||b||: with a recycled space to project on, the projection's multi-dot of b returns <b,b> as well -- one pass, one
+    // reduction and one host round trip less per stage
+    static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
+    int first_space = -1;
+    std::vector<double> g_first(6, 0.0);
+    if (rec_on && stage > 0)
+        for (int q = 0; q < stage && first_space < 0; q++) {
+            bool use = h->rec_mode == 2;
+            for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
+            if (use && h->rec[q].valid && h->rec[q].pc == pcmode) first_space = q;
+        }
+    if (first_space >= 0) {
+        const ksfd_handle::RecSpace &S = h->rec[first_space];
+        if ((rc = op_multidot(h, b, h->V + (int64_t)S.vb * vs, S.k + 1))) return rc;
+        for (int i = 0; i <= S.k + 1; i++) g_first[i] = h->hres[i];
+    } else if ((rc = op_multidot(h, b, V, 0))) return rc;
+    const double bn = sqrt(first_space >= 0 ? g_first[h->rec[first_space].k + 1] : h->hres[0]);
     ls->its = 0; ls->rel = 0.0;
     if (!(bn > 0.0)) {
         if (bn != bn) return fail(h, KSFD_ENAN, "GMRES: right-hand side is not finite");
@@ -198,7 +213,6 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     double *const Xbase = use_poly ? h->Zb : h->V;          // slot 0 of the basis the solution is expanded in
     const int xslot0 = use_poly ? zb : vb;                  // first slot of this solve's own vectors
     if (rec_on && stage > 0) {
-        static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
         for (int q = 0; q < stage; q++) {
             bool use = h->rec_mode == 2;
             for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
@@ -207,8 +221,12 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             const double *Vs = h->V + (int64_t)S.vb * vs;
             const double *Zs = use_poly ? h->Zb + (int64_t)S.zb * vs : Vs;
             double gq[5], yq[4], Hy[5], neg[5];
-            if ((rc = op_multidot(h, rsrc, Vs, S.k + 1))) return rc;
-            for (int i = 0; i <= S.k; i++) gq[i] = h->hres[i];
+            if (q == first_space && rsrc == b) {
+                for (int i = 0; i <= S.k; i++) gq[i] = g_first[i];                 // already computed together with ||b||
+            } else {
+                if ((rc = op_multidot(h, rsrc, Vs, S.k + 1))) return rc;
+                for (int i = 0; i <= S.k; i++) gq[i] = h->hres[i];
+            }
             hess_lsq(S.H, S.k, gq, yq, Hy);
             if (use_pc) {
                 if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
