@@ -213,6 +213,13 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     double *const Xbase = use_poly ? h->Zb : h->V;          // slot 0 of the basis the solution is expanded in
     const int xslot0 = use_poly ? zb : vb;                  // first slot of this solve's own vectors
     if (rec_on && stage > 0) {
+        int last_space = -1;                                  // its residual update also returns the norm of the result
+        for (int q = 0; q < stage; q++) {
+            bool use = h->rec_mode == 2;
+            for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
+            if (use && h->rec[q].valid && h->rec[q].pc == pcmode) last_space = q;
+        }
+        bool have_norm = false;
         for (int q = 0; q < stage; q++) {
             bool use = h->rec_mode == 2;
             for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
@@ -244,12 +251,13 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             if (rsrc == b) {
                 const double *xs[6] = { b }; double a[6] = { 1.0 };
                 for (int i = 0; i <= S.k; i++) { xs[i + 1] = Vs + (int64_t)i * vs; a[i + 1] = neg[i]; }
-                if ((rc = op_lincomb(h, S.k + 2, xs, a, h->t3))) return rc;
+                if ((rc = op_lincomb(h, S.k + 2, xs, a, h->t3, q == last_space))) return rc;
                 rsrc = h->t3;
-            } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0))) return rc;
+            } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0, q == last_space))) return rc;
+            have_norm = q == last_space;
         }
         if (x_set || x0_pending) {
-            if ((rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
+            if (!have_norm && (rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
             beta = rn = sqrt(h->hres[0]);
             if (!(beta == beta)) return fail(h, KSFD_ENAN, "GMRES: projected residual is not finite");
         }

@@ -305,20 +305,23 @@ static inline bool vec2(const ksfd_handle *h) { return (h->G.nloc % 2 == 0) && (
 static inline dim3 vgridw(const ksfd_handle *h, int vw) { return dim3((h->nblk_vec + vw - 1) / vw, h->G.F); }
 #define VW_DISPATCH(h, CALL) do { if (vec2(h)) { constexpr int VW = 2; CALL; } else { constexpr int VW = 1; CALL; } } while (0)
 
-static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const double *a, double *out)
+// want_norm: ||out||^2 lands in h->hres[0] (one reduction instead of a pass of its own)
+static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const double *a, double *out, bool want_norm = false)
 {
+    double *part = want_norm ? h->part : nullptr;
     KLin L;
     for (int t = 0; t < 6; t++) { L.x[t] = t < nt ? x[t] : nullptr; L.a[t] = t < nt ? a[t] : 0.0; }
     Scope sc(h, KC_LINCOMB, vbytes(h, nt + 1));
     switch (nt) {
-    case 1: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<1, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 2: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<2, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 3: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<3, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 4: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    case 5: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<5, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
-    default: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<6, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out)); break;
+    case 1: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<1, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out, part)); break;
+    case 2: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<2, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out, part)); break;
+    case 3: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<3, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out, part)); break;
+    case 4: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out, part)); break;
+    case 5: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<5, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out, part)); break;
+    default: VW_DISPATCH(h, hipLaunchKernelGGL((k_lincomb<6, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, L, out, part)); break;
     }
     HIPCHK(h, hipGetLastError());
+    if (want_norm) { const dim3 gr = vgridw(h, vec2(h) ? 2 : 1); return reduce_rows(h, 1, (int)(gr.x * gr.y), 0); }
     return KSFD_OK;
 }
 
@@ -365,17 +368,19 @@ static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const
     return KSFD_OK;
 }
 
-static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta)
+static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta, bool want_norm = false)
 {
+    double *part = want_norm ? h->part : nullptr;
     KCoef C;
     int nread = 0;                                      // vectors with a zero coefficient are not loaded
     for (int i = 0; i < KSFD_MAXDOT; i++) { C.h[i] = i < k ? coef[i] : 0.0; nread += C.h[i] != 0.0; }
     Scope sc(h, KC_BASISAXPY, vbytes(h, nread + 1 + (beta != 0.0)));
-    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
-    else VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta));
+    if (k <= 4) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<4, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta, part));
+    else if (k <= 8) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<8, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta, part));
+    else if (k <= 16) VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<16, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta, part));
+    else VW_DISPATCH(h, hipLaunchKernelGGL((k_basis_axpy<32, VW>), vgridw(h, VW), dim3(KSFD_BLOCK), 0, h->st, h->kv, x, V, h->vlen, k, C, beta, part));
     HIPCHK(h, hipGetLastError());
+    if (want_norm) { const dim3 gr = vgridw(h, vec2(h) ? 2 : 1); return reduce_rows(h, 1, (int)(gr.x * gr.y), 0); }
     return KSFD_OK;
 }
 

@@ -88,15 +88,31 @@ template <int VW> __device__ __forceinline__ void kstore(double *p, const typena
 
 // out = sum_t a[t] * x[t]   (NT <= 6 inputs; out may alias any x[t]).  Used for the ROSW stage
 // vectors (VecMAXPY/VecWAXPY in PETSc's TSStep_RosW) and the GMRES solution update.
+// sum of v over the block -> *dst (wave shuffle tree, one LDS hop across the waves); every thread of the block must call it
+__device__ __forceinline__ void ksfd_block_sum_to(double v, double *dst)
+{
+    __shared__ double red_[KSFD_BLOCK / KSFD_WAVE];
+    v = ksfd_wave_sum(v);
+    if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red_[threadIdx.x / KSFD_WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) t += red_[q];
+        *dst = t;
+    }
+}
+
 struct KLin {
     const double *x[6];
     double a[6];
 };
 template <int NT, int VW>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_lincomb(KVec g, KLin L, double *out)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_lincomb(KVec g, KLin L, double *out, double *part = nullptr)
 {
+    // part != NULL: also the block's share of ||out||^2 -> part[blockIdx.y*gridDim.x + blockIdx.x] (k_reduce_rows finishes it)
     const long long base = (long long)blockIdx.y * g.plane + g.off;
     const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    double nrm = 0.0;
     for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
         typename KPack<VW>::T s, xv;
 #pragma unroll
@@ -108,7 +124,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_lincomb(KVec g, KLin L, double *
             for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) + L.a[t] * kget(xv, e));
         }
         kstore<VW>(out + base + p, s);
+#pragma unroll
+        for (int e = 0; e < VW; e++) nrm += kget(s, e) * kget(s, e);
     }
+    if (part) ksfd_block_sum_to(nrm, part + (long long)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Krylov dot products: d[i] = <w, V_i> for i < k, and d[k] = <w, w>, in ONE pass over w.
@@ -286,10 +305,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_gs_update(KVec g, double *__rest
 template <int KMAX, int VW>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_basis_axpy(KVec g, double *__restrict__ x,
                                                            const double *__restrict__ V, long long vstride, int k,
-                                                           KCoef C, double beta)
+                                                           KCoef C, double beta, double *part = nullptr)
 {
     const long long base = (long long)blockIdx.y * g.plane + g.off;
     const long long stride = (long long)gridDim.x * blockDim.x * VW;
+    double nrm = 0.0;
     for (long long p = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VW; p < g.nloc; p += stride) {
         typename KPack<VW>::T s;
         if (beta == 0.0) {
@@ -308,7 +328,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_basis_axpy(KVec g, double *__res
                 for (int e = 0; e < VW; e++) kset(s, e, kget(s, e) + C.h[i] * kget(vv, e));
             }
         kstore<VW>(x + base + p, s);
+#pragma unroll
+        for (int e = 0; e < VW; e++) nrm += kget(s, e) * kget(s, e);
     }
+    if (part) ksfd_block_sum_to(nrm, part + (long long)blockIdx.y * gridDim.x + blockIdx.x);     // ||x||^2 share, see k_lincomb
 }
 
 // Step completion (PETSc TSEvaluateStep_RosW + TSErrorWeightedNorm, restated):
