@@ -119,6 +119,11 @@ struct ksfd_handle {
 
     // multigrid preconditioner
     std::vector<MGLevel> mg;
+    double mg_shift_floor = 0.0;  // lower bound on the shift the multigrid hierarchy is built for (see gmres)
+    // online search for that floor (ksfd_step): hill climbing in log2(floor) on the iterations per step
+    int sf_dir = 0, sf_hold = 0;  // +1 doubling, -1 halving, 0 settled (and steps to wait before the next probe)
+    bool sf_tried_down = false, sf_auto = true;
+    double sf_prev_its = 0.0, sf_prev_floor = 0.0;
     bool mg_fuse = true;         // smoother algebra inside the Jacobian-action epilogues (modes 5/6)
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
     double mg_shift = -1.0;      // shift the block diagonals / eigen-bounds were built for

@@ -157,6 +157,10 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                  const ksfd_step_opts *o, LinStats *ls, int pcmode, int stage = -1)
 {
     const bool use_pc = pcmode == 1;       // multigrid, right preconditioning
+    // the hierarchy may be built for a LARGER shift than the system's (h->mg_shift_floor): when 1/(gamma h) falls below the growth
+    // rate of the chemotactic instability, shift*I - J is indefinite and a V cycle of it is no contraction; the V cycle of the
+    // positively shifted operator still is, and GMRES (true residual of the real system) takes care of the difference
+    const double shift_pc = std::max(shift, h->mg_shift_floor);
     const bool use_poly = pcmode == 2;     // Chebyshev polynomial, flexible GMRES (z_j kept in Zb)
     // use_pc: right preconditioning with one multigrid V cycle, w = A (M^-1 v_j), x = M^-1 (V y)
     auto apply_A = [&](const double *vin, double *wout) -> int {
@@ -236,7 +240,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             }
             hess_lsq(S.H, S.k, gq, yq, Hy);
             if (use_pc) {
-                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
+                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift_pc, h->t2, h->t1))) return rc;
                 if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
                 else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
                 x_set = true;
@@ -291,7 +295,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         for (; j < m && total < maxit; j++) {
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
             if (use_pc) {
-                if ((rc = mg_precond(h, shift, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
+                if ((rc = mg_precond(h, shift_pc, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
             } else if (use_poly) {
                 double *zj = Zq + (int64_t)j * vs;
                 if ((rc = poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
@@ -372,7 +376,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
             y[i] = s / H[(size_t)(m + 1) * i + i];
         }
         if (use_pc) {
-            if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift, h->t2, h->t1))) return rc;
+            if ((rc = op_basis_axpy(h, h->t2, V, j, y.data(), 0.0)) || (rc = mg_precond(h, shift_pc, h->t2, h->t1))) return rc;
             if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
             else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
         } else if (x0_pending) {

@@ -508,6 +508,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
 {
     if (!h || !t || !hstep || !opts) return KSFD_EINVAL;
     hipSetDevice(h->device);
+    if (getenv("KSFD_PC_SIGMA")) { h->mg_shift_floor = atof(getenv("KSFD_PC_SIGMA")); h->sf_auto = false; }      // experiment knob: fixed floor
     ksfd_step_stats st;
     memset(&st, 0, sizeof st);
     const double bytes0 = h->bytes_acc;
@@ -561,6 +562,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                                (h->size == 1 || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
         const bool fuse_stage = fused_ok(h) && h->P.nlig <= 4 && h->fuse_stage;
+        const int its_before = st.linear_its;
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
             if (fuse_stage) {
@@ -602,6 +604,32 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, 1);
                 st.linear_its += ls.its;
                 st.ksp_resid = ls.rel;
+            }
+        }
+        if (!rc && use_pc && h->sf_auto) {
+            // Shift floor of the multigrid hierarchy (gmres(): shift_pc = max(shift, floor)).  Once 1/(gamma h) has fallen below the
+            // growth rate of the chemotactic instability the V cycle of shift*I - J stops contracting and the iteration count explodes
+            // (options81 run, h ~ 350: 480 iterations per step; with a floor of 0.2: 120).  The right floor is a property of J we do
+            // not know, so it is searched online: when a step needs > 64 iterations, double the floor while that pays (> 5 % fewer
+            // iterations), else go back and try halving, else settle for 25 steps.
+            const double its = (double)(st.linear_its - its_before);
+            if (h->sf_dir == 0) {
+                if (h->sf_hold > 0) h->sf_hold--;
+                else if (its > 64.0) {
+                    h->sf_prev_its = its; h->sf_prev_floor = h->mg_shift_floor;
+                    h->mg_shift_floor = 2.0 * std::max(h->mg_shift_floor, shift);
+                    h->sf_dir = 1; h->sf_tried_down = false;
+                }
+            } else if (its < 0.95 * h->sf_prev_its) {
+                h->sf_prev_its = its; h->sf_prev_floor = h->mg_shift_floor;
+                h->mg_shift_floor = h->sf_dir > 0 ? 2.0 * h->mg_shift_floor : 0.5 * h->mg_shift_floor;
+                if (h->mg_shift_floor <= shift) { h->sf_dir = 0; h->sf_hold = 25; }          // floor no longer active
+            } else {
+                h->mg_shift_floor = h->sf_prev_floor;
+                if (h->sf_dir > 0 && !h->sf_tried_down && 0.5 * h->sf_prev_floor > shift) {
+                    h->sf_dir = -1; h->sf_tried_down = true;
+                    h->mg_shift_floor = 0.5 * h->sf_prev_floor;
+                } else { h->sf_dir = 0; h->sf_hold = 25; }
             }
         }
         if (rc == KSFD_ELINEAR && opts->adapt && max_rej >= 0 && rejects < max_rej && hh * 0.25 >= opts->dt_min) {
