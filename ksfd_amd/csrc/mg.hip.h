@@ -7,7 +7,7 @@
 // iteration preconditioned by the inverse of the point-block (F x F) diagonal of A_l.  Vertex-centred full
 // coarsening on the periodic box, full-weighting restriction, bilinear prolongation, V(nu,nu) cycle, fixed
 // polynomial smoothing on the coarsest grid -- every piece is a fixed linear operator, so plain
-// right-preconditioned GMRES applies.  2-D and 3-D, single rank or slab ranks.
+// right-preconditioned GMRES applies.  1-D, 2-D and 3-D, single rank or slab ranks.
 #pragma once
 #include "stencil.hip.h"
 
@@ -51,6 +51,39 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long 
             const double *q = coarse + (long long)c * cplane + coff;
             const double v = 0.25 * (q[I + nxc * J] + q[I1 + nxc * J] + q[I + nxc * J1] + q[I1 + nxc * J1]);
             fine[(long long)c * fplane + foff + p] += v;
+        }
+    }
+}
+
+// 1-D transfer operators (the slab axis is x itself): weights (1/4, 1/2, 1/4) and linear interpolation; the axis wraps
+// (one rank) or reads the ghost points at local index -1 / nf (slab ranks).
+__global__ void __launch_bounds__(KSFD_BLOCK) k_restrict1d(int nplanes, long long nf, int wrap,
+                                                           const double *__restrict__ fine, long long fplane, long long foff,
+                                                           double *__restrict__ coarse, long long cplane, long long coff)
+{
+    const long long nc = nf >> 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nc; p += stride) {
+        const long long i0 = 2 * p;
+        const long long im = wrap ? (i0 + nf - 1) % nf : i0 - 1, ip = wrap ? (i0 + 1) % nf : i0 + 1;
+        for (int c = 0; c < nplanes; c++) {
+            const double *f = fine + (long long)c * fplane + foff;
+            coarse[(long long)c * cplane + coff + p] = 0.5 * f[i0] + 0.25 * (f[im] + f[ip]);
+        }
+    }
+}
+__global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add1d(int nplanes, long long nf, int wrap,
+                                                              const double *__restrict__ coarse, long long cplane, long long coff,
+                                                              double *__restrict__ fine, long long fplane, long long foff)
+{
+    const long long nc = nf >> 1;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < nf; p += stride) {
+        const long long I = p >> 1;
+        const long long I1 = (p & 1) ? (wrap ? (I + 1) % nc : I + 1) : I;
+        for (int c = 0; c < nplanes; c++) {
+            const double *q = coarse + (long long)c * cplane + coff;
+            fine[(long long)c * fplane + foff + p] += 0.5 * (q[I] + q[I1]);
         }
     }
 }

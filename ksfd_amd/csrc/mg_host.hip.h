@@ -20,7 +20,6 @@ static void mg_free(ksfd_handle *h)
 
 static int mg_build(ksfd_handle *h)
 {
-    if (h->G.dim < 2) return KSFD_OK;
     const int dim = h->G.dim;
     int nl = h->P.nlig, F = h->G.F;
     long long nx = h->G.nx, ny = dim == 3 ? h->G.ny : 1, rows = h->G.sloc;   // rows = local slow units (y rows in 2-D, z planes in 3-D)
@@ -30,7 +29,8 @@ static int mg_build(ksfd_handle *h)
     for (int l = 0;; l++) {
         MGLevel L;
         L.G = h->G; L.G.nx = nx;
-        if (dim == 2) { L.G.ny = rows; L.G.inner = nx; } else { L.G.ny = ny; L.G.nz = rows; L.G.inner = nx * ny; }
+        if (dim == 1) { L.G.nx = rows; L.G.inner = 1; }                      // 1-D: the slab axis is x itself
+        else if (dim == 2) { L.G.ny = rows; L.G.inner = nx; } else { L.G.ny = ny; L.G.nz = rows; L.G.inner = nx * ny; }
         L.G.sloc = rows;
         L.G.plane = (rows + 2 * L.G.ng) * L.G.inner; L.G.nloc = rows * L.G.inner;
         L.P = P;
@@ -46,7 +46,7 @@ static int mg_build(ksfd_handle *h)
         h->mg.push_back(L);
         // next level: every rank keeps >= 4 slow units (ghost width 2 + the 4th-order star), global grid >= 8 per axis
         const long long rows_glob = rows * h->size;
-        if ((nx % 2) || (rows % 2) || nx / 2 < 8 || rows_glob / 2 < 8 || (h->size > 1 && rows / 2 < 4)) break;
+        if ((dim > 1 && ((nx % 2) || nx / 2 < 8)) || (rows % 2) || rows_glob / 2 < 8 || (h->size > 1 && rows / 2 < 4)) break;
         if (dim == 3 && ((ny % 2) || ny / 2 < 8)) break;
         nx /= 2; rows /= 2;
         if (dim == 3) ny /= 2;
@@ -61,7 +61,10 @@ static int mg_build(ksfd_handle *h)
 static void mg_launch_restrict(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *fine, double *coarse)
 {
     int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    if (Lf.G.dim == 3)
+    if (Lf.G.dim == 1)
+        hipLaunchKernelGGL(k_restrict1d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.sloc, Lf.G.wrap_slow,
+                           fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
+    else if (Lf.G.dim == 3)
         hipLaunchKernelGGL(k_restrict3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
                            fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
     else
@@ -71,7 +74,10 @@ static void mg_launch_restrict(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np,
 static void mg_launch_prolong(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *coarse, double *fine)
 {
     int nb = (int)std::min<long long>((Lf.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    if (Lf.G.dim == 3)
+    if (Lf.G.dim == 1)
+        hipLaunchKernelGGL(k_prolong_add1d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.sloc, Lf.G.wrap_slow,
+                           coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
+    else if (Lf.G.dim == 3)
         hipLaunchKernelGGL(k_prolong_add3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
                            coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
     else

@@ -310,3 +310,19 @@ def test_fused_multigrid_smoother_gives_the_same_iterates(shape):
     assert out['fused'][0] == out['separate'][0]
     assert rel_l2(out['fused'][1], out['separate'][1]) < 1e-11
     k.close()
+
+
+@pytest.mark.parametrize('n,h', [(96, 5.0), (384, 50.0), (130, 2.0)])
+def test_multigrid_1d_stiff_step_vs_oracle_lu(n, h):
+    """1-D hierarchy (weights 1/4, 1/2, 1/4 / linear interpolation; four of the six option files the reference ships are 1-D)"""
+    cfg = ProblemConfig.standard(1, (n,), L=(n / 384.0,), nlig=2)
+    rng = np.random.default_rng(8)
+    rho = 9000 + 90 * rng.standard_normal(n)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(2)])
+    un, err, wr, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=1))
+    assert rel_l2(k.get_state(), un) < 1e-9
+    assert st.linear_its <= 4 * 30, st.linear_its
+    k.close()

@@ -9,7 +9,8 @@ nst = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 cfg = ProblemConfig.standard(2, (384, 384), L=(1.0, 1.0), nlig=2)
 ks = klib.KSFDHip(cfg)
 ks.set_state(z['u'])
-opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
+import os
+opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_restart=int(os.environ.get('KSFD_RESTART', '30')))
 t, h = float(z['t']), float(z['h'])
 ks.synchronize(); T0 = time.perf_counter(); its = 0; rej = 0
 for s in range(nst):
