@@ -1,5 +1,5 @@
 """Solver experiments on the late, slowly converging phase of the 384^2 run: 30 adaptive steps from the saved state."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 from ksfd_amd import lib as klib
@@ -9,6 +9,8 @@ nst = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 cfg = ProblemConfig.standard(2, (384, 384), L=(1.0, 1.0), nlig=2)
 ks = klib.KSFDHip(cfg)
 ks.set_state(z['u'])
+if os.environ.get('KSFD_MG_POWER'):
+    ks.set_mg_params(power_its=int(os.environ['KSFD_MG_POWER']))
 import os
 opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_restart=int(os.environ.get('KSFD_RESTART', '30')))
 t, h = float(z['t']), float(z['h'])
