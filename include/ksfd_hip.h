@@ -208,6 +208,9 @@ int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the
  * Chebyshev bound, smoothing interval ratio lambda_max/lambda_min, coarsest-grid reduction target */
 int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t power_its, double ratio, double coarse_tol);
+/* The hierarchy is built for max(shift, floor)*I - J; the floor is searched online by ksfd_step when 1/(gamma h) has fallen
+ * below the growth rate of the instability and the iteration count explodes.  Environment KSFD_PC_SIGMA=<x> fixes it
+ * instead (0 = no floor) -- an experiment knob, not part of the ABI. */
 /* Chebyshev polynomial preconditioner: highest degree (default 6, at most 7; 0 = off), the residual reduction per
  * outer iteration that picks the degree (default 0.02; <= 0 keeps), and the stiffness h*gamma*lambda_max(diffusion)
  * above which pc_type 2 hands over to multigrid (default 75; <= 0 keeps) */
