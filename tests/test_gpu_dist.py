@@ -105,7 +105,7 @@ def _run(size, shape, nlig, transport, tmp_path):
     for k in ('rhs', 'jvp', 'csr_jv'):
         assert rel_l2(z['got_' + k], z['ref_' + k]) < 1e-11, k
     assert rel_l2(z['got_state'], z['ref_state']) < 1e-9          # includes one h=5 step solved to ksp_rtol=1e-11
-    if len(shape) == 2 or shape == (16, 16, 32):
+    if len(shape) <= 2 or shape == (16, 16, 32):
         # the slab hierarchy may be shallower than the single-rank one, never dramatically worse
         assert z['got_mg_its'] <= 2 * z['ref_mg_its'] + 8, (z['got_mg_its'], z['ref_mg_its'])
     for k in ('vmax', 'worms', 't', 'h'):
@@ -114,7 +114,8 @@ def _run(size, shape, nlig, transport, tmp_path):
 
 @pytest.mark.parametrize('size,shape,nlig', [(2, (64, 48), 1), (3, (40, 36), 2), (2, (16, 12, 16), 1), (2, (33, 16), 1),
                                              (2, (140, 160), 1), (3, (64, 240), 2),    # >= 3 row segments per rank -> halo/compute overlap path
-                                             (2, (16, 16, 32), 1)])                    # 3-D with a 2-level multigrid hierarchy on the slabs
+                                             (2, (16, 16, 32), 1),                     # 3-D with a 2-level multigrid hierarchy on the slabs
+                                             (2, (96,), 2)])                           # 1-D slabs with the 1-D multigrid hierarchy
 def test_slab_ranks_match_single_rank_host_transport(size, shape, nlig, tmp_path):
     _run(size, shape, nlig, 'host', tmp_path)
 
