@@ -124,6 +124,29 @@ def rccl_cdist(rank, size, device, group=None):
     return d
 
 
+def transport_selftest(ks, cfg, rank, size, tol=1e-9):
+    """End-to-end check of a freshly created multi-rank handle: the ligand equation f_U = -gamma U + s rho + D lap(U) on a
+    state that is constant in rho and varies only along the slab axis needs the ghost units of both neighbours; the expected
+    rows follow from the GLOBAL 1-D profile with numpy.  True if this rank's slab comes out right."""
+    dim, F = cfg.dim, cfg.F
+    n_slow = cfg.n[dim - 1]
+    lo, hi = slab_range(n_slow, rank, size)
+    inner = int(np.prod(cfg.n[:dim - 1])) if dim > 1 else 1
+    j = np.arange(n_slow)
+    g = 8000.0 + 500.0 * np.sin(2 * np.pi * j / n_slow) + 100.0 * np.cos(6 * np.pi * j / n_slow)
+    hs = cfg.L[dim - 1] / n_slow
+    d2 = (-np.roll(g, 2) + 16 * np.roll(g, 1) - 30 * g + 16 * np.roll(g, -1) - np.roll(g, -2)) / (12 * hs * hs)
+    planes = [np.full((hi - lo) * inner, 9000.0)]
+    for l in range(cfg.nlig):
+        planes.append(np.repeat(g[lo:hi], inner))
+    f = ks.rhs(np.concatenate(planes)).reshape(F, -1)
+    ok = True
+    for l in range(cfg.nlig):
+        want = np.repeat(-cfg.lig_gamma[l] * g[lo:hi] + cfg.lig_s[l] * 9000.0 + cfg.lig_D[l] * d2[lo:hi], inner)
+        ok = ok and bool(np.all(np.abs(f[l + 1] - want) <= tol * np.abs(want).max()))
+    return ok
+
+
 def open_handle(cfg, rank, size, device, transport='auto', group=None, host_group=None):
     """Create this rank's KSFDHip.  transport: 'rccl', 'host' or 'auto' (RCCL, falling back to the host
     callbacks when RCCL cannot be initialised on every rank; the decision is agreed across ranks).
@@ -138,6 +161,8 @@ def open_handle(cfg, rank, size, device, transport='auto', group=None, host_grou
         try:
             d = rccl_cdist(rank, size, device, group)
             ks = klib.KSFDHip(cfg, d)
+            if not transport_selftest(ks, cfg, rank, size):       # ghost units from both ring neighbours, checked against numpy
+                ok, why = 0, 'RCCL halo self-test failed on rank %d' % rank
         except Exception as e:            # noqa: BLE001
             ok, why = 0, repr(e)
         flag = torch.tensor([ok], dtype=torch.int32)

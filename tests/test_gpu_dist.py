@@ -45,6 +45,8 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
             return
         mine = lambda a: local_slab(a, cfg, rank, size)
         got = {}
+        from ksfd_amd.dist import transport_selftest
+        assert transport_selftest(ks, cfg, rank, size)            # the check open_handle runs on the RCCL transport
         got['rhs'] = gather_slabs(ks.rhs(mine(u)), cfg)
         got['jvp'] = gather_slabs(ks.jvp(mine(v), mine(u)), cfg)
         ks.set_state(mine(u))
