@@ -2,29 +2,82 @@
 """bench.py -- grid-point-updates/s of the implicit Keller-Segel step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a launcher: this script starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+   --master-addr 127.0.0.1 ... bench.py ...` itself, before anything touches the GPU, and relays rank 0's line)
 
-A "step" is one implicit time step (KSFDTS.solve loop body, KSFD/ksfdts.py:207-228: groom -> 4-stage
-ROSW RA34PW2 step with matrix-free GMRES -> CFL velocity check) of the BASELINE.json headline config:
-2-D 4096^2, one ligand, fp64, synthetic random-perturbation initial data, state resident
-in HBM.  The SAME global grid is slab-decomposed over the N GPUs (strong scaling).
+A "step" is one implicit time step (KSFDTS.solve loop body, KSFD/ksfdts.py:207-228: groom -> 4-stage ROSW RA34PW2 step
+with matrix-free preconditioned GMRES -> CFL velocity check) of the BASELINE.json headline config: 2-D 4096^2, one
+ligand, fp64, options84 physics/spacing, synthetic random-perturbation initial data, state resident in
+HBM.  The SAME global grid is slab-decomposed over the N GPUs (strong scaling).
 
-One JSON line on rank 0, with `roofline` for the dominant kernel (algorithmic bytes per launch / HIP-event
-time per launch measured on the library's compute stream during the timed region) and `cpu_baseline`
-(the oracle's restatement of the same step, timed on the host cores on a bounded sub-grid sample).
+What is timed (so that `value` does not depend on --steps/--warmup: the controller lets h grow 7 orders of magnitude
+over a run, and a step at h = 1 costs several times a step at h = 1e-3):
+
+  setup (untimed for `value`, reported as `ramp`): the adaptive run from the reference's dt0 = 1e-8 (options84:10) with
+      TSAdaptBasic rtol = 1e-6, atol = 0.01 (options84:18-19) up to model time t* = --t-star (default 0.35).  The state,
+      the proposed step and the solver's step-to-step memory at t* are checkpointed on the device.
+  primary `value`: K steps walking cyclically through the PINNED WINDOW = the next --window (5) adaptive steps from that
+      checkpoint (ksfd_checkpoint restore at every wrap-around: one device copy, inside the timed region).  Every
+      window is the same work, so any K that is a multiple of the window gives the same number; W warm-up steps walk the
+      same window first.  value = N_grid * K / wall.
+  `fixed_h`: 100 steps at h = 1e-3 from the start values (SURVEY.md 8d's second run), its own rate.
+
+One JSON line on rank 0, with `roofline` for the dominant kernel class of the timed region (HIP events on the library's
+compute stream) and `cpu_baseline` (the oracle's restatement of the same step, timed on the host cores on a bounded
+sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--grid', dest='n', type=int, default=4096, help='points per axis')
+    ap.add_argument('--nlig', type=int, default=1)
+    ap.add_argument('--dim', type=int, default=2, help='2 (headline) or 3 (BASELINE configs[4]-style)')
+    ap.add_argument('--dt0', type=float, default=1e-8, help='first trial step of the ramp (options84:10)')
+    ap.add_argument('--t-star', type=float, default=0.35,
+                    help='model time at which the pinned window starts (0.35: the window then spans h ~ 0.1-0.3, the regime BENCH_r01 measured)')
+    ap.add_argument('--window', type=int, default=5, help='adaptive steps in the pinned window')
+    ap.add_argument('--fixed-h', type=float, default=1e-3, help='step of the fixed-h leg (SURVEY.md 8d); 0 skips it')
+    ap.add_argument('--fixed-steps', type=int, default=100)
+    ap.add_argument('--ksp-rtol', type=float, default=0.0, help='GMRES relative residual; 0 = library default')
+    ap.add_argument('--pc-type', type=int, default=-1, help='ksfd_step_opts.pc_type; -1 = library default (automatic)')
+    ap.add_argument('--transport', default=os.environ.get('KSFD_TRANSPORT', 'auto'), choices=['auto', 'rccl', 'host'])
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend for launch/timing; gloo + --transport host lets several ranks share one GPU (rehearsal)')
+    ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-n', type=int, default=1024)
+    ap.add_argument('--yseg', type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a CHILD process group (never exec from a process
+    that has touched the GPU; this parent imports neither torch nor the library), relay output and exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def build_problem(n, nlig, spacing_ref=4.0 / 1536, dim=2):
@@ -35,40 +88,27 @@ def build_problem(n, nlig, spacing_ref=4.0 / 1536, dim=2):
     return ProblemConfig.standard(dim, (n,) * dim, L=(L,) * dim, nlig=nlig)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--grid', dest='n', type=int, default=4096, help='points per axis')
-    ap.add_argument('--nlig', type=int, default=1)
-    ap.add_argument('--dim', type=int, default=2, help='2 (headline) or 3 (BASELINE configs[4]-style, generic kernels)')
-    ap.add_argument('--dt', type=float, default=0.01, help='first trial step (the controller adapts from here)')
-    ap.add_argument('--fixed-h', type=float, default=0.0, help='>0: -ts_adapt_type none with this step')
-    ap.add_argument('--ksp-rtol', type=float, default=1e-6,
-                    help='GMRES relative residual; 1e-6 keeps the fields within ~1e-10 rel-L2 of a 1e-12 solve')
-    ap.add_argument('--transport', default=os.environ.get('KSFD_TRANSPORT', 'auto'), choices=['auto', 'rccl', 'host'])
-    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
-                    help='torch.distributed backend for launch/timing; gloo + --transport host lets several ranks share one GPU (rehearsal)')
-    ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-n', type=int, default=3072)
-    ap.add_argument('--yseg', type=int, default=0)
-    args = ap.parse_args()
+PC_NAMES = {1: 'none', 2: 'multigrid', 4: 'polynomial', 8: 'spectral'}
 
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from ksfd_amd import lib as klib
     from ksfd_amd.dist import open_handle
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run' % (args.gpus, world),
-                  file=sys.stderr)
-        sys.exit(2)
     host_group = None
     dev = 0 if (world == 1 or args.share_gpu) else local_rank
     if world > 1:
@@ -88,21 +128,23 @@ def main():
         ks.set_poly_params(int(os.environ['KSFD_POLY_DEG']), float(os.environ.get('KSFD_POLY_TARGET', '0')))
     if os.environ.get('KSFD_TUNE'):                      # A/B switches of ksfd_set_tuning (tools/async_bench.py)
         ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
+
     # synthetic start values of SURVEY.md 8d, interpolated on the device slab by slab from the global coarse samples
     # (seed 793817931, n/4 coarse normal noise sigma=90 around rho=9000, U = rho*s/gamma): ksfd_set_state_random
     from ksfd_amd.initial import reference_rng
-    ks.set_state_random(reference_rng().normal(size=tuple(max(1, n // 4) for n in cfg.n[:cfg.dim])) * 90.0, 9000.0)
+    zc = reference_rng().normal(size=tuple(max(1, n // 4) for n in cfg.n[:cfg.dim])) * 90.0
 
-    if args.fixed_h > 0:
-        opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=args.ksp_rtol)
-        h = args.fixed_h
-    else:
-        opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=args.ksp_rtol)   # options84:18-19
-        h = args.dt
-    t = 0.0
+    def opts_for(adapt):
+        o = klib.default_step_opts(adapt=adapt, atol=0.01, rtol=1e-6)        # options84:18-19
+        if args.ksp_rtol > 0:
+            o.ksp_rtol = args.ksp_rtol
+        if args.pc_type >= 0:
+            o.pc_type = args.pc_type
+        return o
+
     spacing = cfg.spacing
 
-    def one_step(t, h):
+    def one_step(t, h, opts):
         t, h, st, rc = ks.step(t, h, opts)                   # groom + ROSW/GMRES step (+ rejections)
         vmax = ks.velocity_max()                              # CFL_check, KSFD/ksfdts.py:287-319
         cfl = min(s * 2 / v if v > 0 else float('inf') for s, v in zip(spacing, vmax[:cfg.dim]))
@@ -114,13 +156,85 @@ def main():
         torch.cuda.synchronize()
         ks.synchronize()
 
-    # Warm-up steps run with a HIP-event pair around every launch: per-class table + which class dominates.  Every
-    # event pair costs ~8 us of device time, so the timed region keeps events only around the dominant class (the
-    # one the roofline object describes); the launch/byte counters of the other classes keep running.
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    class Tally:
+        def __init__(self):
+            self.steps = self.its = self.rej = 0
+            self.hs, self.pcs, self.bytes = [], {}, 0.0
+
+        def add(self, st):
+            self.steps += 1
+            self.its += st.linear_its
+            self.rej += st.rejections
+            self.hs.append(st.h_used)
+            self.bytes += st.bytes
+            for bit, nm in PC_NAMES.items():
+                if st.pc_used & bit:
+                    self.pcs[nm] = self.pcs.get(nm, 0) + 1
+
+        def summary(self):
+            return {'steps': self.steps, 'gmres_its_per_step': self.its / max(self.steps, 1), 'rejections': self.rej,
+                    'h_min': float(np.min(self.hs)), 'h_max': float(np.max(self.hs)), 'h_mean': float(np.mean(self.hs)),
+                    'steps_by_preconditioner': self.pcs}
+
+    # ---------------- fixed-h leg: 100 steps at h = 1e-3 from the start values
+    fixed = None
+    if args.fixed_h > 0 and args.fixed_steps > 0:
+        ks.set_state_random(zc, 9000.0)
+        o = opts_for(0)
+        t, h = 0.0, args.fixed_h
+        for _ in range(3):
+            t, h, st, cfl = one_step(t, args.fixed_h, o)
+        barrier()
+        t0 = time.perf_counter()
+        tal = Tally()
+        for _ in range(args.fixed_steps):
+            t, h, st, cfl = one_step(t, args.fixed_h, o)
+            tal.add(st)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        fixed = {'h': args.fixed_h, 'steps': args.fixed_steps, 'ms_per_step': 1e3 * el / args.fixed_steps,
+                 'value': cfg.N * args.fixed_steps / el, 'gmres_its_per_step': tal.its / args.fixed_steps,
+                 'steps_by_preconditioner': tal.pcs}
+
+    # ---------------- ramp from dt0 to t* (setup of the pinned window; reported, not the headline)
+    ks.set_state_random(zc, 9000.0)
+    o = opts_for(1)
+    t, h = 0.0, args.dt0
+    barrier()
+    t0 = time.perf_counter()
+    tal = Tally()
+    while t < args.t_star and tal.steps < 400:
+        t, h, st, cfl = one_step(t, h, o)
+        tal.add(st)
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    ramp = dict(tal.summary(), dt0=args.dt0, t_end=t, seconds=el, value=cfg.N * tal.steps / el, ms_per_step=1e3 * el / tal.steps)
+    t_star, h_star = t, h
+    ks.checkpoint()
+
+    # ---------------- pinned window: warm-up with events on every launch (per-class table), then the timed region with
+    # events only around the dominant class (each event pair costs ~8 us of device time)
+    def walk(nsteps, tally=None):
+        t, h = t_star, h_star
+        for i in range(nsteps):
+            if i % args.window == 0:
+                ks.restore()
+                t, h = t_star, h_star
+            t, h, st, cfl = one_step(t, h, o)
+            if tally is not None:
+                tally.add(st)
+        return t
+
     ks.set_profiling(True)
     ks.profile(reset=True)
-    for _ in range(args.warmup):
-        t, h, st, cfl = one_step(t, h)
+    walk(args.warmup)
     warm = ks.profile(reset=True)
     skip = ('halo', 'reduce', 'misc')                       # transport / tiny kernels are not roofline material
     dom = max((k for k in warm if k not in skip), key=lambda k: warm[k]['ms']) if args.warmup > 0 else None
@@ -131,62 +245,62 @@ def main():
         dom = names[int(pick.item())]
     ks.set_profiling(not os.environ.get('KSFD_BENCH_NOPROF'), only=dom)      # env knob: A/B the cost of the events
     ks.profile(reset=True)
+    tal = Tally()
     barrier()
     t_start = time.perf_counter()
-    its, rej, hs, nbytes = 0, 0, [], 0.0
-    for _ in range(args.steps):
-        t, h, st, cfl = one_step(t, h)
-        its += st.linear_its
-        rej += st.rejections
-        hs.append(st.h_used)
-        nbytes += st.bytes
+    t_last = walk(args.steps, tal)
     barrier()
-    elapsed = time.perf_counter() - t_start
+    elapsed = max_over_ranks(time.perf_counter() - t_start)
     prof = ks.profile()
     ks.set_profiling(False)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
     if rank == 0:
         N = cfg.N
         value = N * args.steps / elapsed
-        # dominant kernel = largest share of device time in the timed region
         if dom is None:
             dom = max((k for k in prof if k not in skip), key=lambda k: prof[k]['ms'])
         d = prof[dom]
-        per_launch_bytes = d['bytes'] / max(d['launches'], 1)
-        per_launch_ms = d['ms'] / max(d['launches'], 1)
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        nl = max(d['launches'], 1)
+        per_launch_ms = d['ms'] / nl
+        impl_bytes, alg_bytes = d['bytes'] / nl, d['alg_bytes'] / nl
+        gbs = lambda b: b / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         table = warm if args.warmup > 0 else prof             # all-class timings: warm-up steps (see above)
-        kern = {k: dict(ms=round(v['ms'], 3), launches=int(v['launches']),
+        tot_ms = sum(v['ms'] for v in table.values()) or 1.0
+        kern = {k: dict(ms=round(v['ms'], 3), launches=int(v['launches']), share=round(v['ms'] / tot_ms, 3),
                         GBs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
                 for k, v in table.items() if v['launches']}
-        # the committed PMC summary was taken on the default workload only
-        default_workload = world == 1 and args.n == 4096 and args.dim == 2 and args.nlig == 1 and args.fixed_h == 0
+        default_workload = world == 1 and args.n == 4096 and args.dim == 2 and args.nlig == 1
         traffic, traffic_src = pmc_traffic(dom) if default_workload else (None, None)
+        rp_us, rp_src = rocprof_avg_us(dom) if default_workload else (None, None)
         out = {
             'metric': 'grid-point-updates/sec (implicit step)', 'value': value, 'unit': 'grid-point-updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%dD %s %d-ligand Keller-Segel, ROSW RA34PW2 + matrix-free GMRES(30,CGS2), '
-                                   'options84 spacing/physics, %s' % (args.dim, 'x'.join([str(args.n)] * args.dim), args.nlig,
-                                                                      'fixed h=%g' % args.fixed_h if args.fixed_h > 0 else
-                                                                      'TSAdaptBasic rtol=1e-6 atol=0.01 from dt=%g' % args.dt),
-                       'grid': [args.n] * args.dim, 'fields': cfg.F, 'ksp_rtol': args.ksp_rtol,
-                       'h_mean': float(np.mean(hs)), 'gmres_its_per_step': its / args.steps, 'rejections': rej,
-                       't_end': t, 'parallelism': 'slab%d' % world, 'preconditioner': 'Chebyshev polynomial p(A), fp32 storage of its temporaries/coefficient copy (fp64 arithmetic; Krylov vectors, A z_j, solution fp64)' if not (int(os.environ.get('KSFD_TUNE', '1')) & 512) else 'Chebyshev polynomial p(A), fp64',
-                       'transport': type(keep).__name__ if keep is not None else 'none'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'bytes_per_launch': per_launch_bytes, 'ms_per_launch': per_launch_ms,
-                         'step_algorithmic_GBs': nbytes / elapsed / 1e9,
-                         'step_frac_of_peak': nbytes / elapsed / 1e9 / HBM_PEAK_GBS},
+            'config': dict({'workload': '%dD %s %d-ligand Keller-Segel (options84 spacing/physics), implicit step = ROSW RA34PW2 + '
+                                        'matrix-free preconditioned GMRES(30) + CFL check; pinned window: the %d TSAdaptBasic '
+                                        '(rtol=1e-6, atol=0.01) steps that follow model time t*=%g of the run from dt0=%g, '
+                                        'walked cyclically' % (args.dim, 'x'.join([str(args.n)] * args.dim), args.nlig,
+                                                               args.window, args.t_star, args.dt0),
+                             'grid': [args.n] * args.dim, 'fields': cfg.F, 'ksp_rtol': float(o.ksp_rtol), 'pc_type': int(o.pc_type),
+                             't_star': t_star, 'h_star': h_star, 'window': args.window, 't_end_of_window': t_last,
+                             'parallelism': 'slab%d' % world, 'transport': getattr(ks, 'transport_name', 'none'),
+                             'rccl_error': getattr(ks, 'rccl_error', None)}, **tal.summary()),
+            'roofline': {'bound': 'hbm', 'kernel': dom,
+                         # `achieved`/`frac`: ALGORITHMIC bytes per launch (Jacobian action 24*F*N) / HIP-event time per launch
+                         'achieved': gbs(alg_bytes), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs(alg_bytes) / HBM_PEAK_GBS,
+                         'frac_algorithmic': gbs(alg_bytes) / HBM_PEAK_GBS,
+                         # bytes the implementation has to move per launch (frozen-coefficient planes, fused operands)
+                         'frac_implementation': gbs(impl_bytes) / HBM_PEAK_GBS,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'alg_bytes_per_launch': alg_bytes, 'impl_bytes_per_launch': impl_bytes, 'ms_per_launch': per_launch_ms,
+                         'launches': int(d['launches']), 'rocprof_avg_us': rp_us, 'rocprof_source': rp_src,
+                         'step_implementation_GBs': tal.bytes / elapsed / 1e9,
+                         'step_frac_of_peak': tal.bytes / elapsed / 1e9 / HBM_PEAK_GBS},
+            'ramp': ramp, 'fixed_h': fixed,
             'kernels': kern, 'kernels_region': 'warmup steps (events on every launch)' if args.warmup > 0 else 'timed steps',
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, float(np.mean(hs)))
+            out['cpu_baseline'] = cpu_baseline(args, float(np.mean(tal.hs)))
         print(json.dumps(out), flush=True)
     ks.close()
     if world > 1:
@@ -209,6 +323,20 @@ def pmc_traffic(kernel_class):
         return None, None
 
 
+def rocprof_avg_us(kernel_class):
+    """Average duration of this class' kernels in the newest committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/*_pmc.json carries it as 'avg_us' per class; tools/summarize_prof.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+    if not files:
+        return None, None
+    try:
+        c = json.load(open(files[-1]))['classes'].get(kernel_class)
+        return (c.get('avg_us'), os.path.basename(files[-1])) if c else (None, None)
+    except Exception:
+        return None, None
+
+
 def usable_cores():
     """Host cores this process may really use: cgroup quota if there is one, else the affinity mask,
     capped at 16 (the GPU box's CPU share per GPU; its affinity mask shows all 256 hardware threads)."""
@@ -223,9 +351,10 @@ def usable_cores():
 
 
 def cpu_baseline(args, h):
-    """The oracle's restatement of the same step (kind 'port'), OpenMP over the host cores this process may
-    use, on a bounded sample: ONE step at the GPU run's mean h on an m x m sub-grid with the same spacing,
-    physics and initial-data statistics."""
+    """The oracle's restatement of the same step (kind 'port': ROSW + unpreconditioned GMRES(30), classic CGS2), OpenMP over
+    the host cores this process may use, on a bounded sample: ONE step at the pinned window's mean h on an m x m sub-grid
+    with the same spacing, physics and initial-data statistics.  The iteration count of the unpreconditioned solve grows
+    with h, so the iteration cap bounds the leg (a step that hits the cap is reported as such, with its partial rate)."""
     from ksfd_amd.initial import start_values
     from oracle import ko
     m = args.cpu_sample_n
@@ -236,13 +365,19 @@ def cpu_baseline(args, h):
     cores = usable_cores()
     ko.set_threads(cores)
     o = ko.Oracle(cfg)
+    rt = args.ksp_rtol if args.ksp_rtol > 0 else 1e-6
     t0 = time.perf_counter()
-    un, err, wr, its = o.rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=args.ksp_rtol, restart=30, maxit=2000)
+    note = ''
+    try:
+        un, err, wr, its = o.rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=rt, restart=30, maxit=1200)
+        note = '%d GMRES its' % its
+    except RuntimeError:
+        note = 'iteration cap (1200) reached: rate is an upper bound'
     dt = time.perf_counter() - t0
     ko.set_threads(1)
     return {'value': cfg.N / dt, 'unit': 'grid-point-updates/s', 'cores': cores, 'kind': 'port',
-            'sample': 'one ROSW+GMRES(30,CGS2) step at h=%.4g on a %s sub-grid (same spacing/physics/IC '
-                      'statistics), %d GMRES its, %.1f s' % (h, 'x'.join([str(m)] * args.dim), its, dt)}
+            'sample': 'one ROSW+GMRES(30,CGS2, no preconditioner) step at h=%.4g on a %s sub-grid (same spacing/physics/IC '
+                      'statistics), %s, %.1f s' % (h, 'x'.join([str(m)] * args.dim), note, dt)}
 
 
 if __name__ == '__main__':

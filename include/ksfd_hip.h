@@ -101,7 +101,8 @@ typedef struct ksfd_step_stats {
     int32_t rejections;
     int32_t linear_its;         /* GMRES iterations over all stages and attempts */
     int32_t rhs_evals, jvp_evals;
-    int32_t reserved;
+    int32_t pc_used;            /* preconditioners the stage solves of this call ran with, OR of: 1 none, 2 multigrid V cycle,
+                                 * 4 Chebyshev polynomial, 8 spectral (constant-coefficient FFT) */
     double wrms;                /* error norm of the last attempt */
     double h_used;              /* step actually taken (valid when accepted) */
     double ksp_resid;           /* last relative residual */
@@ -109,11 +110,13 @@ typedef struct ksfd_step_stats {
 } ksfd_step_stats;
 
 /* Per-kernel-class timing gathered with HIP events on the library's compute stream. */
-#define KSFD_NKCLASS 13
+#define KSFD_NKCLASS 14
 typedef struct ksfd_profile {
     double ms[KSFD_NKCLASS];       /* accumulated device time */
-    double bytes[KSFD_NKCLASS];    /* accumulated algorithmic bytes */
+    double bytes[KSFD_NKCLASS];    /* accumulated bytes the IMPLEMENTATION must move (e.g. frozen-coefficient planes included) */
     int64_t launches[KSFD_NKCLASS];
+    double alg_bytes[KSFD_NKCLASS];/* accumulated ALGORITHMIC bytes of the same launches (RHS 16*F*N,
+                                    * Jacobian action 24*F*N, vector passes = operands * 8*F*N) */
 } ksfd_profile;
 const char *ksfd_kernel_class_name(int32_t cls);
 
@@ -145,6 +148,10 @@ int ksfd_snapshot_wait(ksfd_handle *h, int32_t slot, const double **host);
  * nc[0..2], x fastest, periodic; the caller draws them from numpy's default_rng so the stream matches ksfdrandom.py:44-49),
  * U_l = rho*s_l/gamma_l (:636-637). */
 int ksfd_set_state_random(ksfd_handle *h, const int64_t nc[3], const double *z_coarse_host, double rho0);
+/* Device-side checkpoint of the state together with what the solver remembers from step to step (spectral-radius estimate,
+ * preconditioner adaptation): op 0 = save, op 1 = restore.  One slot, allocated on first use.  Used by bench.py to time a
+ * pinned window of steps repeatedly and by callers that want to retry from a known state without a host round trip. */
+int ksfd_checkpoint(ksfd_handle *h, int32_t op);
 double *ksfd_device_state(ksfd_handle *h);      /* device pointer, SoA with ghost rows; plane stride below */
 int64_t ksfd_device_plane_stride(const ksfd_handle *h);
 int64_t ksfd_device_interior_offset(const ksfd_handle *h);

@@ -5,9 +5,9 @@
 // ------------------------------------------------------------------------------------------------
 // kernel classes for the profile
 enum { KC_RHS = 0, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE,
-       KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG };
+       KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG, KC_SPECTRAL };
 static const char *kc_names[KSFD_NKCLASS] = { "rhs", "jvp", "multidot", "gs_update", "lincomb", "basis_axpy",
-                                              "rosw_finish", "reduce", "gfield", "velocity", "misc", "halo", "mg" };
+                                              "rosw_finish", "reduce", "gfield", "velocity", "misc", "halo", "mg", "spectral" };
 extern "C" const char *ksfd_kernel_class_name(int32_t c) { return (c >= 0 && c < KSFD_NKCLASS) ? kc_names[c] : "?"; }
 
 static thread_local std::string g_create_error;
@@ -49,6 +49,10 @@ struct ksfd_handle {
     int64_t vlen = 0;
     double *u = nullptr, *usave = nullptr, *Z = nullptr, *bvec = nullptr, *Y = nullptr, *V = nullptr;
     double *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *errv = nullptr;
+    double *ckpt = nullptr;                 // ksfd_checkpoint slot (allocated on first save)
+    struct SolverMemo { double lamJ; int lam_age, lam_period; double mg_shift_floor; int sf_dir, sf_hold; bool sf_tried_down; double sf_prev_its, sf_prev_floor; };
+    SolverMemo ckpt_memo;
+    bool ckpt_valid = false;
     double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes
     double *coef = nullptr;                 // frozen-Jacobian coefficient planes [rho, G, G_rho, G_U..]
     bool use_frozen = true;
@@ -167,10 +171,12 @@ static hipEvent_t ev_get(ksfd_handle *h)
 }
 struct Scope {
     ksfd_handle *h; EvPair p; bool on;
-    Scope(ksfd_handle *h_, int cls, double bytes) : h(h_), on(h_->profiling && !h_->capturing && (h_->prof_only < 0 || h_->prof_only == cls))
+    // alg < 0: the implementation moves exactly the algorithmic bytes
+    Scope(ksfd_handle *h_, int cls, double bytes, double alg = -1.0) : h(h_), on(h_->profiling && !h_->capturing && (h_->prof_only < 0 || h_->prof_only == cls))
     {
         h->bytes_acc += bytes;
         h->prof.bytes[cls] += bytes;
+        h->prof.alg_bytes[cls] += alg < 0.0 ? bytes : alg;
         h->prof.launches[cls] += 1;
         if (on) { p.a = ev_get(h); p.b = ev_get(h); p.cls = cls; hipEventRecord(p.a, h->st); }
     }

@@ -33,7 +33,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->st) hipStreamSynchronize(h->st);
-    double *bufs[] = { h->Zb, h->pvec, h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
+    double *bufs[] = { h->ckpt, h->Zb, h->pvec, h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
     for (double *b : bufs) if (b) hipFree(b);
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
     if (h->coef32) hipFree(h->coef32);
@@ -115,17 +115,33 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     // ~30 other full-size vectors (state, stage vectors, temporaries, coefficient planes, multigrid level 0 + coarse levels)
     // must fit first.  m = 30 on anything up to ~12k^2 x 2 fields on a 288 GB MI355X; larger grids run with a shorter restart.
     h->restart_alloc = 30;
+    int fit_local = 30;
     {
         size_t mfree = 0, mtotal = 0;
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree > 0) {
             const double vecbytes = 8.0 * (double)h->vlen;
             const double room = 0.92 * (double)mfree / vecbytes - 30.0;
-            const int fit = (int)floor((room - 1.0) / 2.0);
-            if (fit < 30) {
-                if (fit < 8) CFAIL(KSFD_ENOMEM, "grid too large for this device: %.1f GB free, a vector is %.2f GB, the solver needs ~47 of them", mfree / 1e9, vecbytes / 1e9);
-                h->restart_alloc = fit;
-            }
+            fit_local = std::min(30, (int)floor((room - 1.0) / 2.0));
         }
+    }
+    if (alloc_d(h, &h->dres, 128)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
+    if (h->size > 1) {
+        std::string terr;
+        h->tr = make_transport(dist, G.F, G.inner, terr);
+        if (!h->tr) CFAIL(KSFD_ECOMM, "transport %d: %s", dist->transport, terr.c_str());
+        // every rank must run with the SAME restart length (the multi-dot row counts and restart points are part of the
+        // collective pattern): take the minimum over the ranks of what each one's free HBM allows
+        double v = -(double)fit_local;
+        if (hipMemcpyAsync(h->dres, &v, sizeof v, hipMemcpyHostToDevice, h->st) != hipSuccess || h->tr->allreduce(h->dres, 1, 1, h->st))
+            CFAIL(KSFD_ECOMM, "agreeing on the restart length failed: %s", h->tr->error().c_str());
+        if (h->tr->result_on_host()) v = h->tr->host_result()[0];
+        else if (hipMemcpyAsync(&v, h->dres, sizeof v, hipMemcpyDeviceToHost, h->st) != hipSuccess || hipStreamSynchronize(h->st) != hipSuccess)
+            CFAIL(KSFD_EHIP, "reading the agreed restart length failed");
+        fit_local = (int)(-v + 0.5);
+    }
+    if (fit_local < 30) {
+        if (fit_local < 8) CFAIL(KSFD_ENOMEM, "grid too large for this device: a vector is %.2f GB, the solver needs ~47 of them (restart length that fits: %d)", 8.0 * (double)h->vlen / 1e9, fit_local);
+        h->restart_alloc = fit_local;
     }
     double **vecs[] = { &h->u, &h->usave, &h->Z, &h->bvec, &h->t1, &h->t2, &h->t3, &h->errv };
     for (double **v : vecs) {
@@ -135,7 +151,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     if (alloc_d(h, &h->Y, 4 * h->vlen) || alloc_d(h, &h->V, (int64_t)(h->restart_alloc + 1) * h->vlen) ||
         alloc_d(h, &h->Gb, G.plane) || alloc_d(h, &h->dGb, G.plane) || alloc_d(h, &h->coef, (int64_t)(3 + cfg->nlig) * G.plane) ||
         alloc_d(h, &h->flat, (int64_t)std::max(G.F, 3) * G.nloc) ||
-        alloc_d(h, &h->part, (int64_t)(2 * KSFD_MAXDOT + 4) * 4096) || alloc_d(h, &h->dres, 128))
+        alloc_d(h, &h->part, (int64_t)(2 * KSFD_MAXDOT + 4) * 4096))
         CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
     hipMemsetAsync(h->Y, 0, sizeof(double) * (size_t)(4 * h->vlen), h->st);
     hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)((h->restart_alloc + 1) * h->vlen), h->st);
@@ -155,11 +171,6 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         for (auto &e : h->gm_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) CFAIL(KSFD_EHIP, "hipEventCreate failed");
     }
 
-    if (h->size > 1) {
-        std::string terr;
-        h->tr = make_transport(dist, G.F, G.inner, terr);
-        if (!h->tr) CFAIL(KSFD_ECOMM, "transport %d: %s", dist->transport, terr.c_str());
-    }
     if (mg_build(h)) { mg_free(h); h->mg_ok = false; }        // out of memory for the hierarchy: run without the multigrid preconditioner
     if (hipStreamSynchronize(h->st) != hipSuccess) CFAIL(KSFD_EHIP, "stream sync failed in create");
 #undef CFAIL
@@ -260,6 +271,27 @@ extern "C" int ksfd_snapshot_wait(ksfd_handle *h, int32_t slot, const double **h
     hipSetDevice(h->device);
     HIPCHK(h, hipEventSynchronize(h->snap_done[slot]));
     *host = h->snap_host[slot];
+    return KSFD_OK;
+}
+
+extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
+{
+    if (!h || op < 0 || op > 1) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    if (op == 0) {
+        if (!h->ckpt && alloc_d(h, &h->ckpt, h->vlen)) return KSFD_ENOMEM;
+        HIPCHK(h, hipMemcpyAsync(h->ckpt, h->u, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
+        h->ckpt_memo = { h->lamJ, h->lam_age, h->lam_period, h->mg_shift_floor, h->sf_dir, h->sf_hold, h->sf_tried_down, h->sf_prev_its, h->sf_prev_floor };
+        h->ckpt_valid = true;
+        return KSFD_OK;
+    }
+    if (!h->ckpt_valid) return fail(h, KSFD_EINVAL, "no checkpoint has been saved");
+    HIPCHK(h, hipMemcpyAsync(h->u, h->ckpt, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
+    const ksfd_handle::SolverMemo &m = h->ckpt_memo;
+    h->lamJ = m.lamJ; h->lam_age = m.lam_age; h->lam_period = m.lam_period; h->mg_shift_floor = m.mg_shift_floor;
+    h->sf_dir = m.sf_dir; h->sf_hold = m.sf_hold; h->sf_tried_down = m.sf_tried_down; h->sf_prev_its = m.sf_prev_its; h->sf_prev_floor = m.sf_prev_floor;
+    h->mg_coef_valid = false; h->mg_shift = -1.0; h->poly_shift = -1.0; h->have_err = false;
+    rec_reset(h);
     return KSFD_OK;
 }
 
@@ -598,10 +630,12 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                            : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0), i);
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
+            st.pc_used |= use_pc ? 2 : (use_poly ? 4 : 1);
             if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
                 // unpreconditioned GMRES ran out of iterations: the multigrid-preconditioned solve of the same system
                 // is the remedy (the stiffness estimate above only knows the diffusion part of J)
                 rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, 1);
+                st.pc_used |= 2;
                 st.linear_its += ls.its;
                 st.ksp_resid = ls.rel;
             }

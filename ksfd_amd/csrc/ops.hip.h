@@ -33,10 +33,9 @@ static int spin_for(ksfd_handle *h, unsigned long long seq)
 
 static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
 {
-    // (single rank only for now: the RCCL variant -- k_publish after the all-reduce -- has never run on real multi-GPU hardware,
-    //  KSFD_ZC_MULTI=1 enables it)
-    static const bool zc_multi = getenv("KSFD_ZC_MULTI") != nullptr;
-    const bool zc = h->zero_copy && !h->capturing && rows <= 128 && (h->size == 1 || zc_multi);
+    // several ranks with a device-side all-reduce (RCCL): a one-block k_publish behind the all-reduce hands the result over
+    // the same way; ksfd_amd.dist.open_handle checks that path end to end on a new handle and clears zero_copy if it fails
+    const bool zc = h->zero_copy && !h->capturing && rows <= 128 && (h->size == 1 || h->tr->device_allreduce());
     const bool zc_here = zc && h->size == 1;
     const unsigned long long seq = zc ? ++h->pub_seq : 0;
     {
@@ -118,7 +117,7 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, (const double *)nullptr, h->Gb, (double *)nullptr));
         }
         int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_RHS, vbytes(h, 2) + 8.0 * (double)G.nloc);
+        Scope sc(h, KC_RHS, vbytes(h, 2) + 8.0 * (double)G.nloc, vbytes(h, 2));
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_rhs_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->Gb, S, out));
     }
     HIPCHK(h, hipGetLastError());
@@ -140,7 +139,7 @@ static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, do
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, true>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb));
         }
         int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_JVP, vbytes(h, 3) + 16.0 * (double)G.nloc);
+        Scope sc(h, KC_JVP, vbytes(h, 3) + 16.0 * (double)G.nloc, vbytes(h, 3));
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, v, h->Gb, h->dGb, mode, shift, out));
     }
     HIPCHK(h, hipGetLastError());
@@ -167,9 +166,10 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
 {
     const KGeom &G = h->G;
     const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
+    const double alg = 8.0 * (3.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc;   // read u, v, write out (+ the fused vector operand)
     if (fused_ok(h)) {
         KStrips K = make_strips(h, true);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc, alg);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta));
     } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
@@ -189,7 +189,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
         long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
         K.nblocks = (int)((nb3 + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc, alg);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
@@ -198,7 +198,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
         }
         int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc);
+        Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc, alg);
         // the generic stencil kernel reads rho from plane 0 of its `u` argument (already clamped in C) and G from C
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jvp_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, (const double *)h->coef, v, (const double *)(h->coef + G.plane), (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     }
@@ -222,6 +222,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
         return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
     }
     const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
+    const double algp = 3.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);
     const int nseg_total = K.nseg;
     HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
     {
@@ -229,7 +230,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
         Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = nseg_total - 2;
         long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
         Ki.nblocks = (int)((nb + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * (double)Ki.nseg / nseg_total);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * (double)Ki.nseg / nseg_total, 8.0 * algp * (double)G.nloc * (double)Ki.nseg / nseg_total);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Ki.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Ki, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
     }
     HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
@@ -244,7 +245,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
         Kb.seg0 = 0; Kb.seg_stride = nseg_total - 1; Kb.nseg = 2;
         long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
         Kb.nblocks = (int)((nb + 7) / 8 * 8);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * 2.0 / nseg_total);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc * 2.0 / nseg_total, 8.0 * algp * (double)G.nloc * 2.0 / nseg_total);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(Kb.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Kb, (const double *)h->coef, (const double *)v, mode, shift, out, yadd, alpha, beta));
     }
     HIPCHK(h, hipGetLastError());
@@ -260,7 +261,7 @@ static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const T
 {
     const KGeom &G = h->G;
     const double per_pt = (3.0 + h->P.nlig) * sizeof(TC) + G.F * (double)(sizeof(TV) + sizeof(TO)) + ((mode == 2 || mode == 3) ? G.F * (double)sizeof(TY) : 0.0);
-    Scope sc(h, KC_JVP, per_pt * (double)G.nloc * frac);
+    Scope sc(h, KC_JVP, per_pt * (double)G.nloc * frac, 8.0 * (3.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc * frac);
     NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, TC, TV, TY, TO>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st,
                                                                      G, h->P, K, C, (const TV *)v, mode, shift, out, yadd, alpha, beta));
     HIPCHK(h, hipGetLastError());

@@ -111,11 +111,13 @@ class HostRing:
         return d
 
 
-def rccl_cdist(rank, size, device, group=None):
-    """transport 1: rank 0 creates the ncclUniqueId, torch.distributed broadcasts it."""
+def rccl_cdist(rank, size, device, group=None, unique_id=None):
+    """transport 1: rank 0 creates the ncclUniqueId, torch.distributed broadcasts it (through `group`: pass the host/gloo
+    group when the default one is NCCL, so no device tensor is involved before the library's own communicator exists)."""
     import torch.distributed as dist
-    box = [klib.rccl_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=group)
+    box = [(unique_id if unique_id is not None else klib.rccl_unique_id()) if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
     buf = C.create_string_buffer(box[0], 128)
     d = klib.CDist()
     d.rank, d.size, d.transport, d.device = rank, size, 1, device
@@ -147,32 +149,92 @@ def transport_selftest(ks, cfg, rank, size, tol=1e-9):
     return ok
 
 
-def open_handle(cfg, rank, size, device, transport='auto', group=None, host_group=None):
-    """Create this rank's KSFDHip.  transport: 'rccl', 'host' or 'auto' (RCCL, falling back to the host
-    callbacks when RCCL cannot be initialised on every rank; the decision is agreed across ranks).
-    Returns (KSFDHip, keepalive)."""
+def reduction_selftest(ks, cfg, rank, size, tol=1e-12):
+    """End-to-end check of the global reduction path of a multi-rank handle (block partials -> all-reduce -> result handed to
+    the host, zero-copy publish included): sum(rho) of a state whose slabs differ per rank."""
+    dim = cfg.dim
+    lo, hi = slab_range(cfg.n[dim - 1], rank, size)
+    inner = int(np.prod(cfg.n[:dim - 1])) if dim > 1 else 1
+    nloc = (hi - lo) * inner
+    planes = [np.full(nloc, 1000.0 + 7.0 * rank)] + [np.full(nloc, 1.0)] * cfg.nlig
+    ks.set_state(np.concatenate(planes))
+    want = sum((1000.0 + 7.0 * r) * nloc for r in range(size))
+    got = ks.count_worms()
+    return bool(abs(got - want) <= tol * want)
+
+
+def _agree(ok, g, device):
+    """MIN over the ranks of a 0/1 flag through the host-side group (every rank must call it at the same points)."""
     import torch
     import torch.distributed as dist
+    flag = torch.tensor([int(bool(ok))], dtype=torch.int32)
+    if dist.get_backend(g) == 'nccl':
+        flag = flag.cuda(device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)
+    return int(flag.item()) == 1
+
+
+def open_handle(cfg, rank, size, device, transport='auto', group=None, host_group=None):
+    """Create this rank's KSFDHip.  transport: 'rccl', 'host' or 'auto' (RCCL, falling back to the host
+    callbacks when RCCL cannot be initialised on every rank; every decision is agreed across ranks BEFORE the next
+    collective step, so a rank that fails early cannot leave its peers blocked inside RCCL).
+    Returns (KSFDHip, keepalive); ks.transport_name is 'none' | 'rccl' | 'host' | 'host-fallback' and ks.rccl_error
+    holds the reason of a fallback."""
     if size == 1:
-        return klib.KSFDHip(cfg), None
+        ks = klib.KSFDHip(cfg)
+        ks.transport_name, ks.rccl_error = 'none', None
+        return ks, None
     g = host_group if host_group is not None else group
+    why = ''
     if transport in ('auto', 'rccl'):
-        ok, ks, d, why = 1, None, None, ''
+        ks, d = None, None
+        # 1. librccl resolvable on every rank (creating an id nobody uses is harmless)
+        uid = None
         try:
-            d = rccl_cdist(rank, size, device, group)
-            ks = klib.KSFDHip(cfg, d)
-            if not transport_selftest(ks, cfg, rank, size):       # ghost units from both ring neighbours, checked against numpy
-                ok, why = 0, 'RCCL halo self-test failed on rank %d' % rank
+            uid = klib.rccl_unique_id()
+            ok = True
         except Exception as e:            # noqa: BLE001
-            ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        if dist.get_backend(g) == 'nccl':
-            flag = flag.cuda(device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)
-        if int(flag.item()) == 1:
+            ok, why = False, 'rank %d: %r' % (rank, e)
+        ok = _agree(ok, g, device)
+        # 2. communicator + device buffers (ncclCommInitRank is collective: entered by all ranks or by none)
+        if ok:
+            try:
+                d = rccl_cdist(rank, size, device, g, unique_id=uid)
+                ks = klib.KSFDHip(cfg, d)
+            except Exception as e:        # noqa: BLE001
+                ok, why = False, 'rank %d: %r' % (rank, e)
+            ok = _agree(ok, g, device)
+        # 3. ghost units from both ring neighbours, checked against numpy
+        if ok:
+            try:
+                ok = transport_selftest(ks, cfg, rank, size)
+                why = '' if ok else 'RCCL halo self-test failed on rank %d' % rank
+            except Exception as e:        # noqa: BLE001
+                ok, why = False, 'rank %d: %r' % (rank, e)
+            ok = _agree(ok, g, device)
+        # 4. global reductions; the zero-copy hand-over to the host is dropped (on every rank) if it is what fails
+        if ok:
+            def red_ok():
+                try:
+                    return reduction_selftest(ks, cfg, rank, size)
+                except Exception:         # noqa: BLE001
+                    return False
+            ok = _agree(red_ok(), g, device)
+            if not ok:
+                ks.set_tuning(use_fused=1 | 2048)          # bit 11: stream synchronisation + copy instead of the mapped-memory flag
+                ks.zero_copy_disabled = True
+                ok = _agree(red_ok(), g, device)
+                why = '' if ok else 'RCCL all-reduce self-test failed'
+        if ok:
+            ks.transport_name, ks.rccl_error = 'rccl', None
             return ks, d
         if ks is not None:
             ks.close()
+        # the reason of whichever rank failed, for the log / bench line
+        import torch.distributed as dist
+        reasons = [None] * size
+        dist.all_gather_object(reasons, why, group=g)
+        why = '; '.join(r for r in reasons if r) or 'unknown'
         if transport == 'rccl':
             raise RuntimeError('RCCL transport unavailable: ' + why)
         if rank == 0:
@@ -180,4 +242,6 @@ def open_handle(cfg, rank, size, device, transport='auto', group=None, host_grou
     ring = HostRing(g)
     ks = klib.KSFDHip(cfg, ring.cdist(device))
     ks._ring = ring
+    ks.transport_name = 'host-fallback' if transport == 'auto' else 'host'
+    ks.rccl_error = why or None
     return ks, ring

@@ -13,13 +13,14 @@ from .layout import PETSC, SOA, HDF5  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libksfd_hip.so')
-NKCLASS = 13
+NKCLASS = 14
 
 OK, EINVAL, EHIP, ENOMEM, ELINEAR, ENAN, EREJECT, ECOMM = range(8)
 
 # kernel classes of ksfd_profile / ksfd_bench_kernel
 KC_RHS, KC_JVP, KC_MULTIDOT, KC_GSUPDATE, KC_LINCOMB, KC_BASISAXPY, KC_FINISH, KC_REDUCE, \
-    KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG = range(13)
+    KC_GFIELD, KC_VELOCITY, KC_MISC, KC_HALO, KC_MG, KC_SPECTRAL = range(14)
+PC_NONE, PC_MULTIGRID, PC_POLYNOMIAL, PC_SPECTRAL = 1, 2, 4, 8      # bits of StepStats.pc_used
 
 
 class KSFDError(RuntimeError):
@@ -50,12 +51,13 @@ class StepOpts(C.Structure):
 
 class StepStats(C.Structure):
     _fields_ = [('accepted', C.c_int32), ('rejections', C.c_int32), ('linear_its', C.c_int32),
-                ('rhs_evals', C.c_int32), ('jvp_evals', C.c_int32), ('reserved', C.c_int32),
+                ('rhs_evals', C.c_int32), ('jvp_evals', C.c_int32), ('pc_used', C.c_int32),
                 ('wrms', C.c_double), ('h_used', C.c_double), ('ksp_resid', C.c_double), ('bytes', C.c_double)]
 
 
 class Profile(C.Structure):
-    _fields_ = [('ms', C.c_double * NKCLASS), ('bytes', C.c_double * NKCLASS), ('launches', C.c_int64 * NKCLASS)]
+    _fields_ = [('ms', C.c_double * NKCLASS), ('bytes', C.c_double * NKCLASS), ('launches', C.c_int64 * NKCLASS),
+                ('alg_bytes', C.c_double * NKCLASS)]
 
 
 _lib = None
@@ -65,7 +67,7 @@ ABI_SYMBOLS = [
     'ksfd_kernel_class_name', 'ksfd_rccl_unique_id', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
     'ksfd_local_range', 'ksfd_local_size', 'ksfd_set_state', 'ksfd_get_state', 'ksfd_device_state',
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
-    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr', 'ksfd_set_state_random', 'ksfd_snapshot_begin', 'ksfd_snapshot_wait',
+    'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr', 'ksfd_set_state_random', 'ksfd_snapshot_begin', 'ksfd_snapshot_wait', 'ksfd_checkpoint',
     'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
     'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params', 'ksfd_set_poly_params',
 ]
@@ -112,6 +114,7 @@ def load():
     L.ksfd_mul_rho.argtypes = [vp, dp]
     L.ksfd_snapshot_begin.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     L.ksfd_snapshot_wait.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(C.c_double))]
+    L.ksfd_checkpoint.argtypes = [vp, C.c_int32]
     L.ksfd_set_state_random.argtypes = [vp, C.POINTER(C.c_int64), dp, C.c_double]
     L.ksfd_jacobian_nnz.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ksfd_jacobian_csr.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp]
@@ -269,6 +272,13 @@ class KSFDHip:
         self._chk(self.L.ksfd_snapshot_wait(self.h, slot, C.byref(ptr)))
         return np.ctypeslib.as_array(ptr, shape=(self.nlocal,))
 
+    def checkpoint(self):
+        """device-side copy of the state + the solver's step-to-step memory (one slot)"""
+        self._chk(self.L.ksfd_checkpoint(self.h, 0))
+
+    def restore(self):
+        self._chk(self.L.ksfd_checkpoint(self.h, 1))
+
     def set_state_random(self, z_coarse, rho0=9000.0):
         """start_values on the device: z_coarse indexed [i,j,k] (x first) on the global coarse grid (ksfdsolver2.py:580-639)"""
         z = np.asarray(z_coarse, dtype=np.float64)
@@ -319,7 +329,7 @@ class KSFDHip:
         p = Profile()
         self._chk(self.L.ksfd_get_profile(self.h, C.byref(p), int(reset)))
         names = [self.L.ksfd_kernel_class_name(i).decode() for i in range(NKCLASS)]
-        return {n: dict(ms=p.ms[i], bytes=p.bytes[i], launches=p.launches[i]) for i, n in enumerate(names)}
+        return {n: dict(ms=p.ms[i], bytes=p.bytes[i], launches=p.launches[i], alg_bytes=p.alg_bytes[i]) for i, n in enumerate(names)}
 
     def synchronize(self):
         self._chk(self.L.ksfd_synchronize(self.h))

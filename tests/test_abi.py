@@ -33,7 +33,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(klib.CConfig) == 16 + 24 + 24 + 48 + 56
     assert ctypes.sizeof(klib.StepOpts) == 8 * 2 + 8 + 8 * 8 + 16
     assert ctypes.sizeof(klib.StepStats) == 24 + 32
-    assert ctypes.sizeof(klib.Profile) == 13 * 8 * 3
+    assert ctypes.sizeof(klib.Profile) == klib.NKCLASS * 8 * 4 and klib.NKCLASS == 14
 
 
 def test_no_gpu_fails_loudly():

@@ -51,9 +51,7 @@ def test_translation_invariance_and_linearity_at_baseline_sizes(shape, nlig, shi
     for l in range(nlig):
         want = -cfg.lig_gamma[l] * (8000.0 + 100 * l) + cfg.lig_s[l] * 9000.0
         assert np.allclose(fc[(l + 1) * cfg.N:(l + 2) * cfg.N], want, rtol=1e-9, atol=0)
-    if cfg.N > 5e7:                                           # 8192^2 x 3 fields: keep the host footprint bounded
-        k.close()
-        return
+    del fc, fs, f
     rng = np.random.default_rng(2)
     v1, v2 = rng.standard_normal(u.size), rng.standard_normal(u.size)
     k.set_state(u)
@@ -89,3 +87,58 @@ def test_step_of_a_tiled_state_is_the_tiled_step():
     assert abs(st_b.wrms - wrms_small) <= 1e-6 * wrms_small              # the WRMS norm is a mean: tiling leaves it alone
     # the step did something: rho moved by far more than the agreement asked for above
     assert rel_l2(got[:big.N], tile(us)[:big.N]) > 1e-6
+
+
+def _tile(x, F, small_shape, reps):
+    """periodic replication of a flat SoA state: (F, [nz,] ny, nx) tiled `reps` times along every axis"""
+    a = x.reshape((F,) + tuple(reversed(small_shape)))
+    return np.tile(a, (1,) + (reps,) * len(small_shape)).reshape(-1)
+
+
+@pytest.mark.parametrize('small,reps,nlig,hs', [
+    ((1024, 1024), 8, 2, (1e-3, 0.1)),      # BASELINE configs[3]: 8192^2, 3 fields; h = 1e-3 plain GMRES, h = 0.1 polynomial regime (X ~ 19)
+    ((64, 64, 64), 8, 1, (1e-3, 0.05)),     # BASELINE configs[4]: 512^3, 2 fields, 13-point star
+])
+def test_full_size_configs_are_tilings_of_small_ones(small, reps, nlig, hs):
+    """RHS, Jacobian action and whole implicit steps of the 8192^2 x 3 and 512^3 problems equal the periodic tiling of the
+    1024^2 / 64^3 problem with the same spacing and physics (options84:32-46; 9/13-point star KSFD/ksfdsym.py:177-178),
+    which the small-size tests tie to the golden vectors.  Host copies are freed as soon as they are compared."""
+    big_shape = tuple(n * reps for n in small)
+    cs, cb = _cfg(small, nlig), _cfg(big_shape, nlig)
+    F = cs.F
+    us = _state(cs, 5)
+    vs = np.random.default_rng(6).standard_normal(us.size)
+    opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
+    ks = klib.KSFDHip(cs)
+    want = {'rhs': ks.rhs(us), 'jvp': ks.jvp(vs, us)}
+    ks.set_state(us)
+    want['jvp_frozen'] = ks.jvp(vs)                       # the stepper's path: frozen coefficient planes of the resident state
+    t = 0.0
+    for i, h in enumerate(hs):
+        t, _, st, rc = ks.step(t, h, opts)
+        want['step%d' % i] = ks.get_state()
+        want['wrms%d' % i] = st.wrms
+    ks.close()
+    kb = klib.KSFDHip(cb)
+    ub = _tile(us, F, small, reps)
+    got = kb.rhs(ub)
+    assert rel_l2(got, _tile(want['rhs'], F, small, reps)) < 1e-13
+    del got
+    vb = _tile(vs, F, small, reps)
+    got = kb.jvp(vb, ub)
+    assert rel_l2(got, _tile(want['jvp'], F, small, reps)) < 1e-13
+    del got
+    kb.set_state(ub)
+    del ub
+    got = kb.jvp(vb)
+    assert rel_l2(got, _tile(want['jvp_frozen'], F, small, reps)) < 1e-13
+    del got, vb
+    t = 0.0
+    for i, h in enumerate(hs):
+        t, _, st, rc = kb.step(t, h, opts)
+        assert st.accepted
+        assert abs(st.wrms - want['wrms%d' % i]) <= 1e-6 * want['wrms%d' % i]
+        got = kb.get_state()
+        assert rel_l2(got, _tile(want['step%d' % i], F, small, reps)) < 1e-10, (i, h)
+        del got
+    kb.close()

@@ -23,7 +23,7 @@ shutil.copy(ks, 'profiles/%s_kernel_stats.csv' % tag)
 CLASS = [('k_rhs', 'rhs'), ('k_jvp', 'jvp'), ('k_multidot', 'multidot'), ('k_gs_update', 'gs_update'),
          ('k_lincomb', 'lincomb'), ('k_basis_axpy', 'basis_axpy'), ('k_rosw_finish', 'rosw_finish'),
          ('k_reduce_rows', 'reduce'), ('k_gfield', 'gfield'), ('k_jcoef', 'gfield'), ('k_dg_frozen', 'gfield'),
-         ('k_velocity', 'velocity')]
+         ('k_velocity', 'velocity'), ('k_spec', 'spectral'), ('k_mg_', 'mg'), ('k_cheb', 'mg'), ('k_restrict', 'mg'), ('k_prolong', 'mg')]
 
 
 def cls_of(name):
@@ -43,6 +43,13 @@ def collect(kind):
     return agg
 
 
+# average duration per kernel class from the --kernel-trace --stats table (weighted by calls)
+dur = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(ks)):
+    c = dur[cls_of(r['Name'].replace('void ', ''))]
+    c[0] += int(r['Calls'])
+    c[1] += float(r['TotalDurationNs'])
+
 fe, wr = collect('fetch'), collect('write')
 kern, classes = {}, collections.defaultdict(lambda: dict(launches=0, fetch_KB=0.0, write_KB=0.0))
 for n in sorted(set(fe) | set(wr)):
@@ -59,7 +66,8 @@ for n in sorted(set(fe) | set(wr)):
 out = dict(source=src, note='HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; see module docstring of tools/summarize_prof.py',
            kernels=kern,
            classes={k: dict(launches=v['launches'],
-                            hbm_bytes_per_launch=(2 * v['fetch_KB'] + v['write_KB']) / v['launches'] * 1024)
+                            hbm_bytes_per_launch=(2 * v['fetch_KB'] + v['write_KB']) / v['launches'] * 1024,
+                            avg_us=(dur[k][1] / dur[k][0] / 1e3) if dur[k][0] else None, trace_calls=dur[k][0])
                     for k, v in classes.items()})
 json.dump(out, open('profiles/%s_pmc.json' % tag, 'w'), indent=1)
 print(open('profiles/%s_kernel_stats.csv' % tag).read()[:1500])
