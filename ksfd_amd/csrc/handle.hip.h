@@ -28,6 +28,21 @@ struct MGLevel {
     double ratio = 60.0;       // lambda_max/lambda_min estimate (used on the coarsest grid)
 };
 
+// spectral preconditioner (spectral.hip.h / spectral_host.hip.h)
+struct SpecState {
+    bool ok = false, means_valid = false;
+    KFFTPlan px, py;
+    int rb = 0, npair = 0;
+    size_t lds_rows = 0, lds_cols = 0;
+    kcf *W = nullptr, *twx = nullptr, *twy = nullptr;
+    int *posx = nullptr, *posy = nullptr;
+    float *lx = nullptr, *ly = nullptr;
+    double a_rr = 0.0, a_rU[KSFD_MAXL] = { 0 };
+    // adaptation: steps (counted by ksfd_step calls) before which the automatic choice leaves it alone after it converged badly
+    long long bad_until = 0;
+    int backoff = 8;
+};
+
 struct ksfd_handle {
     ksfd_config cfg;
     int32_t lig_group[KSFD_MAXL];
@@ -50,7 +65,11 @@ struct ksfd_handle {
     double *u = nullptr, *usave = nullptr, *Z = nullptr, *bvec = nullptr, *Y = nullptr, *V = nullptr;
     double *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *errv = nullptr;
     double *ckpt = nullptr;                 // ksfd_checkpoint slot (allocated on first save)
-    struct SolverMemo { double lamJ; int lam_age, lam_period; double mg_shift_floor; int sf_dir, sf_hold; bool sf_tried_down; double sf_prev_its, sf_prev_floor; };
+    struct SolverMemo { double lamJ; int lam_age, lam_period; double mg_shift_floor; int sf_dir, sf_hold; bool sf_tried_down; double sf_prev_its, sf_prev_floor;
+                        long long nsteps, spec_bad_until; int spec_backoff; };
+    SpecState spec;
+    long long nsteps = 0;                   // ksfd_step calls so far
+    double spec_from = 1.0;                 // stiffness above which pc_type 2 prefers the spectral preconditioner (below: plain GMRES / low-degree polynomial)
     SolverMemo ckpt_memo;
     bool ckpt_valid = false;
     double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes

@@ -161,7 +161,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     // rate of the chemotactic instability, shift*I - J is indefinite and a V cycle of it is no contraction; the V cycle of the
     // positively shifted operator still is, and GMRES (true residual of the real system) takes care of the difference
     const double shift_pc = std::max(shift, h->mg_shift_floor);
-    const bool use_poly = pcmode == 2;     // Chebyshev polynomial, flexible GMRES (z_j kept in Zb)
+    const bool use_poly = pcmode == 2 || pcmode == 3;     // flexible GMRES (z_j = M^-1 v_j kept in Zb): 2 Chebyshev polynomial p(A), 3 spectral (spectral_host.hip.h)
     // use_pc: right preconditioning with one multigrid V cycle, w = A (M^-1 v_j), x = M^-1 (V y)
     auto apply_A = [&](const double *vin, double *wout) -> int {
         return h->use_frozen ? op_jvp_frozen(h, vin, 1, shift, wout) : op_jvp(h, ustate, vin, 1, shift, wout);
@@ -298,7 +298,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 if ((rc = mg_precond(h, shift_pc, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
             } else if (use_poly) {
                 double *zj = Zq + (int64_t)j * vs;
-                if ((rc = poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
+                if ((rc = pcmode == 3 ? spec_apply(h, shift, vj, zj) : poly_apply(h, shift, vj, zj)) || (rc = op_jvp_frozen_halo(h, zj, 1, shift, w))) return rc;
             } else if (h->use_frozen) {
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;

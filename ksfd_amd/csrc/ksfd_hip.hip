@@ -15,11 +15,13 @@
 #include "../../include/ksfd_hip.h"
 #include "stencil.hip.h"
 #include "mg.hip.h"
+#include "spectral.hip.h"
 #include "transport.h"
 
 
 #include "handle.hip.h"
 #include "ops.hip.h"
+#include "spectral_host.hip.h"
 #include "mg_host.hip.h"
 #include "krylov.hip.h"
 
@@ -52,6 +54,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
         if (h->snap_done[q]) hipEventDestroy(h->snap_done[q]);
     }
     mg_free(h);
+    spec_free(h);
     delete h->tr;
     if (h->ev_ready) hipEventDestroy(h->ev_ready);
     if (h->ev_halo) hipEventDestroy(h->ev_halo);
@@ -171,6 +174,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         for (auto &e : h->gm_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) CFAIL(KSFD_EHIP, "hipEventCreate failed");
     }
 
+    spec_build(h);                                            // leaves spec.ok = false where it does not apply (3-D, slab ranks, non power-of-two extents)
     if (mg_build(h)) { mg_free(h); h->mg_ok = false; }        // out of memory for the hierarchy: run without the multigrid preconditioner
     if (hipStreamSynchronize(h->st) != hipSuccess) CFAIL(KSFD_EHIP, "stream sync failed in create");
 #undef CFAIL
@@ -281,7 +285,8 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
     if (op == 0) {
         if (!h->ckpt && alloc_d(h, &h->ckpt, h->vlen)) return KSFD_ENOMEM;
         HIPCHK(h, hipMemcpyAsync(h->ckpt, h->u, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
-        h->ckpt_memo = { h->lamJ, h->lam_age, h->lam_period, h->mg_shift_floor, h->sf_dir, h->sf_hold, h->sf_tried_down, h->sf_prev_its, h->sf_prev_floor };
+        h->ckpt_memo = { h->lamJ, h->lam_age, h->lam_period, h->mg_shift_floor, h->sf_dir, h->sf_hold, h->sf_tried_down, h->sf_prev_its, h->sf_prev_floor,
+                         h->nsteps, h->spec.bad_until, h->spec.backoff };
         h->ckpt_valid = true;
         return KSFD_OK;
     }
@@ -290,6 +295,7 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
     const ksfd_handle::SolverMemo &m = h->ckpt_memo;
     h->lamJ = m.lamJ; h->lam_age = m.lam_age; h->lam_period = m.lam_period; h->mg_shift_floor = m.mg_shift_floor;
     h->sf_dir = m.sf_dir; h->sf_hold = m.sf_hold; h->sf_tried_down = m.sf_tried_down; h->sf_prev_its = m.sf_prev_its; h->sf_prev_floor = m.sf_prev_floor;
+    h->nsteps = m.nsteps; h->spec.bad_until = m.spec_bad_until; h->spec.backoff = m.spec_backoff; h->spec.means_valid = false;
     h->mg_coef_valid = false; h->mg_shift = -1.0; h->poly_shift = -1.0; h->have_err = false;
     rec_reset(h);
     return KSFD_OK;
@@ -559,6 +565,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     if (h->use_frozen && (rc = op_jcoef(h, h->u))) goto out;
     h->mg_coef_valid = false; h->mg_shift = -1.0;
     h->poly_shift = -1.0;
+    h->spec.means_valid = false;
+    h->nsteps++;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
         // stiffness estimate X = h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~60
@@ -568,12 +576,19 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const double stiff = dmax * lap / shift;
         // (measured crossover against the degree-6 polynomial: X ~ 80 on 4096^2, ~ 280 on 1024^2 where the V cycle is latency-bound)
         const double mg_from = h->mg_threshold * ((double)h->G.F * (double)h->G.nloc < 8.0e6 ? 3.0 : 1.0);
-        const bool use_pc = h->mg_ok && h->use_frozen && (opts->pc_type == 1 || (opts->pc_type == 2 && stiff > mg_from));
+        // spectral preconditioner (constant-coefficient part of shift*I - J inverted by FFT): nearly exact while the state is a
+        // smooth perturbation of a uniform one, at any stiffness; pc_type 2 uses it until it converges badly (see below), 4 always
+        bool use_spec = h->spec.ok && h->use_frozen && (opts->pc_type == 4 || (opts->pc_type == 2 && stiff >= h->spec_from && h->nsteps > h->spec.bad_until));
+        if (use_spec) {
+            if (!h->Zb && alloc_d(h, &h->Zb, (int64_t)h->restart_alloc * h->vlen)) { rc = KSFD_ENOMEM; goto out; }
+            if (!h->spec.means_valid && (rc = spec_means(h))) goto out;
+        }
+        const bool use_pc = !use_spec && h->mg_ok && h->use_frozen && (opts->pc_type == 1 || (opts->pc_type == 2 && stiff > mg_from));
         // pipelined solver: latency-bound iterations only (small local problem), not in the tiny-h regime where the
         // Pythagorean norm update cancels heavily (|w|^2/h_n^2 ~ 1/stiff^2) and gmres() takes its explicit second pass
         // polynomial preconditioner in the mildly stiff regime (pc_type 2 = automatic, 3 = polynomial whenever useful)
         bool use_poly = false;
-        if (!use_pc && h->use_frozen && (opts->pc_type == 2 || opts->pc_type == 3) && stiff >= 0.3) {
+        if (!use_spec && !use_pc && h->use_frozen && (opts->pc_type == 2 || opts->pc_type == 3) && stiff >= 0.3) {
             if (!h->Zb && alloc_d(h, &h->Zb, (int64_t)h->restart_alloc * h->vlen)) { rc = KSFD_ENOMEM; goto out; }
             if (!lam_done) {
                 if (h->lamJ < 0.0 || ++h->lam_age >= h->lam_period) {
@@ -590,11 +605,12 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             use_poly = h->poly_deg >= 1 && h->poly_max_deg >= 1;
         }
         const bool small = (double)h->G.F * (double)h->G.nloc <= 6.0e6;
-        const bool use_async = !use_pc && !use_poly && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
+        const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
                                (h->size == 1 || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
         const bool fuse_stage = fused_ok(h) && h->P.nlig <= 4 && h->fuse_stage;
         const int its_before = st.linear_its;
+        bool spec_failed = false;
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
             if (fuse_stage) {
@@ -626,11 +642,26 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             }
             LinStats ls;
+            if (use_spec) {
+                // a handful of iterations when it applies; cap the attempt so that a state it does not suit costs little
+                ksfd_step_opts so = *opts;
+                if (opts->pc_type == 2) so.ksp_max_it = 40;
+                rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, &so, &ls, 3, i);
+                st.pc_used |= 8;
+                if (rc == KSFD_ELINEAR && opts->pc_type == 2) {
+                    spec_failed = true;
+                    st.linear_its += ls.its;
+                    const bool mg_here = h->mg_ok && stiff > 0.3;
+                    rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, mg_here ? 1 : 0);
+                    st.pc_used |= mg_here ? 2 : 1;
+                }
+            } else {
             rc = use_async ? gmres_async(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls)
                            : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0), i);
+            st.pc_used |= use_pc ? 2 : (use_poly ? 4 : 1);
+            }
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
-            st.pc_used |= use_pc ? 2 : (use_poly ? 4 : 1);
             if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
                 // unpreconditioned GMRES ran out of iterations: the multigrid-preconditioned solve of the same system
                 // is the remedy (the stiffness estimate above only knows the diffusion part of J)
@@ -639,6 +670,14 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 st.linear_its += ls.its;
                 st.ksp_resid = ls.rel;
             }
+        }
+        if (use_spec && opts->pc_type == 2) {
+            // adaptation: > 12 iterations per stage system (or a failed attempt) means the coefficients vary too much for the
+            // constant-coefficient inverse; leave it alone for a while (doubling) and let the polynomial / V cycle work
+            if (spec_failed || st.linear_its - its_before > 48) {
+                h->spec.bad_until = h->nsteps + h->spec.backoff;
+                h->spec.backoff = std::min(2 * h->spec.backoff, 512);
+            } else h->spec.backoff = 8;
         }
         if (!rc && use_pc && h->sf_auto) {
             // Shift floor of the multigrid hierarchy (gmres(): shift_pc = max(shift, floor)).  Once 1/(gamma h) has fallen below the
@@ -782,6 +821,26 @@ extern "C" int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double t
     h->poly_shift = -1.0;
     return KSFD_OK;
 }
+extern "C" int ksfd_spectral_apply(ksfd_handle *h, double shift, const double *vh, double *outh, int32_t layout)
+{
+    if (!h || !vh || !outh || !(shift > 0.0)) return KSFD_EINVAL;
+    hipSetDevice(h->device);
+    if (!h->spec.ok) return fail(h, KSFD_EINVAL, "spectral preconditioner not available for this handle (needs 2-D, one rank, power-of-two extents)");
+    int rc;
+    if ((rc = upload(h, vh, layout, h->t2))) return rc;
+    if ((rc = halo(h, h->u)) || (rc = op_jcoef(h, h->u))) return rc;
+    h->mg_coef_valid = false; h->mg_shift = -1.0;
+    if ((rc = spec_means(h)) || (rc = spec_apply(h, shift, h->t2, h->t3))) return rc;
+    return download(h, h->t3, layout, outh);
+}
+extern "C" int ksfd_set_spectral_params(ksfd_handle *h, double from_stiffness, int32_t enable)
+{
+    if (!h) return KSFD_EINVAL;
+    if (from_stiffness > 0.0) h->spec_from = from_stiffness;
+    if (enable == 0) h->spec.bad_until = (1LL << 62);
+    else if (enable > 0) { h->spec.bad_until = 0; h->spec.backoff = 8; }
+    return KSFD_OK;
+}
 extern "C" int ksfd_synchronize(ksfd_handle *h)
 {
     if (!h) return KSFD_EINVAL;
@@ -832,6 +891,7 @@ extern "C" int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, doub
             VW_DISPATCH(h, hipLaunchKernelGGL((k_multidot<8, VW>), dim3(vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, (const double *)h->t3, (const double *)h->V, h->vlen, 8, h->part));
         } break;
         case KC_GSUPDATE: r = op_gs_update(h, h->t3, h->V, 8, coef, 1.0); break;
+        case KC_SPECTRAL: r = spec_apply(h, 10.0, h->Y, h->t3); break;
         case KC_LINCOMB: { const double *xs[3] = { h->u, h->Y, h->Y + h->vlen }; double aa[3] = { 1.0, 0.5, 0.25 }; r = op_lincomb(h, 3, xs, aa, h->t3); } break;
         default: r = fail(h, KSFD_EINVAL, "bench_kernel: class %d not benchable", cls);
         }
@@ -839,7 +899,8 @@ extern "C" int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, doub
         return r;
     };
     if ((rc = halo(h, h->u))) goto done;
-    if (h->use_frozen && cls == KC_JVP && (rc = op_jcoef(h, h->u))) goto done;
+    if (h->use_frozen && (cls == KC_JVP || cls == KC_SPECTRAL) && (rc = op_jcoef(h, h->u))) goto done;
+    if (cls == KC_SPECTRAL && (rc = spec_means(h))) goto done;
     for (int i = 0; i < 3 && !rc; i++) rc = one();
     if (rc) goto done;
     hipEventRecord(a, h->st);

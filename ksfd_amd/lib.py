@@ -70,6 +70,7 @@ ABI_SYMBOLS = [
     'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr', 'ksfd_set_state_random', 'ksfd_snapshot_begin', 'ksfd_snapshot_wait', 'ksfd_checkpoint',
     'ksfd_default_step_opts', 'ksfd_step', 'ksfd_get_last_error_vector', 'ksfd_set_profiling',
     'ksfd_get_profile', 'ksfd_synchronize', 'ksfd_bench_kernel', 'ksfd_set_tuning', 'ksfd_set_mg_params', 'ksfd_set_poly_params',
+    'ksfd_spectral_apply', 'ksfd_set_spectral_params',
 ]
 
 
@@ -129,6 +130,8 @@ def load():
     L.ksfd_set_tuning.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.ksfd_set_mg_params.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]
     L.ksfd_set_poly_params.argtypes = [vp, C.c_int32, C.c_double, C.c_double]
+    L.ksfd_spectral_apply.argtypes = [vp, C.c_double, dp, dp, C.c_int32]
+    L.ksfd_set_spectral_params.argtypes = [vp, C.c_double, C.c_int32]
     _lib = L
     return L
 
@@ -344,6 +347,16 @@ class KSFDHip:
 
     def set_poly_params(self, max_degree, target=0.0, mg_threshold=0.0):
         self._chk(self.L.ksfd_set_poly_params(self.h, int(max_degree), float(target), float(mg_threshold)))
+
+    def spectral_apply(self, shift, v, layout=SOA):
+        """z = (shift*I - J0)^-1 v, J0 = constant-coefficient part of the Jacobian at the resident state (test entry)"""
+        out = np.empty(self.nlocal)
+        v = self._vec(v)
+        self._chk(self.L.ksfd_spectral_apply(self.h, float(shift), _dp(v), _dp(out), layout))
+        return out
+
+    def set_spectral_params(self, from_stiffness=0.0, enable=-1):
+        self._chk(self.L.ksfd_set_spectral_params(self.h, float(from_stiffness), int(enable)))
 
     def set_tuning(self, use_fused=-1, yseg=0, yseg_jvp=None):
         """use_fused: bit0 = fused 2-D kernels, bit1 = recompute (non-frozen) Jacobian action."""

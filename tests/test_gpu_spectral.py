@@ -1,0 +1,129 @@
+"""GPU: the spectral preconditioner (ksfd_amd/csrc/spectral.hip.h).
+
+It is a preconditioner, so the parity statements are (a) the operator itself against a numpy restatement (fft2 + the
+closed-form arrow-block inverse) to fp32 accuracy, and (b) whole implicit steps solved WITH it against the oracle's exact
+sparse-LU step to the usual 1e-10 -- GMRES stops on the true fp64 residual whatever the preconditioner does."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from ksfd_amd import lib as klib
+from ksfd_amd.config import ProblemConfig
+from oracle import ko
+
+pytestmark = pytest.mark.gpu
+GAMMA = 4.3586652150845900e-01
+
+
+def _sym_d2(n, h):
+    th = 2 * np.pi * np.fft.fftfreq(n)
+    return (-30 + 32 * np.cos(th) - 2 * np.cos(2 * th)) / (12 * h * h)
+
+
+def _numpy_spectral(cfg, u, shift, v):
+    """(shift I - J0)^-1 v with J0 from the grid means of rho*G_rho, rho*G_Ul (tophat cap), exact 4th-order symbol"""
+    nx, ny = cfg.n[0], cfg.n[1]
+    F, nl = cfg.F, cfg.nlig
+    ug = np.maximum(u.reshape(F, ny, nx), np.array([cfg.rhomin] + [cfg.Umin] * nl)[:, None, None])
+    rho = ug[0]
+    ms = cfg.maxscale * cfg.s2
+    th = np.tanh((rho - cfg.rhomax) / cfg.cushion)
+    a_rr = np.mean(rho * (cfg.s2 / rho + ms * (1 - th * th) / cfg.cushion))
+    a_rU = []
+    for l in range(nl):
+        g = cfg.lig_group[l]
+        ssum = cfg.grp_alpha[g] + sum(cfg.lig_w[m] * ug[m + 1] for m in range(nl) if cfg.lig_group[m] == g)
+        a_rU.append(np.mean(rho * (-cfg.grp_beta[g] * cfg.lig_w[l] / ssum)))
+    L2 = _sym_d2(nx, cfg.L[0] / nx)[None, :] + _sym_d2(ny, cfg.L[1] / ny)[:, None]
+    vh = np.fft.fft2(v.reshape(F, ny, nx))
+    d = [shift + cfg.lig_gamma[l] - cfg.lig_D[l] * L2 for l in range(nl)]
+    den = shift - a_rr * L2 - sum(a_rU[l] * L2 * cfg.lig_s[l] / d[l] for l in range(nl))
+    z0 = (vh[0] + sum(a_rU[l] * L2 / d[l] * vh[l + 1] for l in range(nl))) / den
+    zs = [z0] + [(vh[l + 1] + cfg.lig_s[l] * z0) / d[l] for l in range(nl)]
+    return np.real(np.fft.ifft2(np.array(zs))).reshape(-1)
+
+
+def _three_ligands(shape, L):
+    """two ligands sharing group 0 (weights) + a repellent in its own group: F = 4 -> two complex pairs"""
+    return ProblemConfig(dim=2, n=shape, L=L, lig_group=[0, 0, 1], lig_w=[1.0, 0.5, 1.0], lig_s=[0.01, 0.02, 0.001],
+                         lig_gamma=[0.01, 0.03, 0.001], lig_D=[1e-6, 3e-6, 1e-5], grp_alpha=[1500.0, 1500.0],
+                         grp_beta=[5.56e-4, -5.56e-4])
+
+
+def _state(cfg, seed, amp=90.0):
+    rng = np.random.default_rng(seed)
+    rho = 9000.0 + amp * rng.standard_normal(cfg.N)
+    return np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1 + 0.01 * rng.standard_normal(cfg.N)) for l in range(cfg.nlig)])
+
+
+@pytest.mark.parametrize('shape,nlig', [((64, 32), 1), ((32, 128), 2), ((256, 512), 1), ((64, 64), 3), ((8192, 32), 1), ((32, 4096), 1)])
+@pytest.mark.parametrize('h', [0.02, 5.0])
+def test_spectral_operator_vs_numpy(shape, nlig, h):
+    L = tuple(n * 4.0 / 1536 for n in shape)
+    cfg = _three_ligands(shape, L) if nlig == 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
+    u = _state(cfg, 3)
+    v = np.random.default_rng(4).standard_normal(u.size)
+    shift = 1.0 / (GAMMA * h)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    got = k.spectral_apply(shift, v)
+    k.close()
+    want = _numpy_spectral(cfg, u, shift, v)
+    assert rel_l2(got, want) < 2e-5              # fp32 FFTs and symbol; it is a preconditioner
+
+
+def test_spectral_unavailable_is_reported():
+    cfg = ProblemConfig.standard(2, (48, 40), L=(0.1, 0.1))             # not powers of two
+    k = klib.KSFDHip(cfg)
+    k.set_state(_state(cfg, 1))
+    with pytest.raises(klib.KSFDError):
+        k.spectral_apply(1.0, np.zeros(2 * cfg.N))
+    # pc_type 4 on such a handle: nothing spectral to use, the step still works
+    t, h, st, rc = k.step(0.0, 0.05, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, pc_type=4))
+    assert st.accepted and not (st.pc_used & klib.PC_SPECTRAL)
+    k.close()
+
+
+@pytest.mark.parametrize('shape,nlig,h', [((64, 32), 1, 0.05), ((32, 64), 2, 0.5), ((64, 64), 1, 20.0), ((64, 32), 3, 0.3)])
+@pytest.mark.parametrize('pc', [4, 2])
+def test_step_with_spectral_preconditioner_vs_oracle_lu(shape, nlig, h, pc):
+    L = tuple(n * 4.0 / 1536 for n in shape)
+    cfg = _three_ligands(shape, L) if nlig == 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
+    u = _state(cfg, 7)
+    o = ko.Oracle(cfg)
+    un, err, wr, _ = o.rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-12, pc_type=pc))
+    assert st.pc_used & klib.PC_SPECTRAL
+    assert st.linear_its <= 4 * 14, st.linear_its           # (to ksp_rtol 1e-12; ~3 per stage at the default 1e-6) a near-uniform state: few iterations at any h
+    assert rel_l2(k.get_state(), un) < 1e-10
+    assert abs(st.wrms - wr) <= 1e-6 * wr
+    k.close()
+
+
+def test_automatic_choice_leaves_the_spectral_preconditioner_when_coefficients_vary():
+    """aggregated state (rho varies by a factor ~30): the constant-coefficient inverse no longer converges in a few
+    iterations; pc_type 2 must notice, fall back inside the step (same answer as the LU oracle) and stay away afterwards"""
+    shape = (64, 64)
+    cfg = ProblemConfig.standard(2, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=1)
+    rng = np.random.default_rng(5)
+    x = np.arange(64)
+    bump = np.exp(-((x[None, :] - 20.0) ** 2 + (x[:, None] - 40.0) ** 2) / 30.0) + np.exp(-((x[None, :] - 50.0) ** 2 + (x[:, None] - 12.0) ** 2) / 20.0)
+    rho = (800.0 + 24000.0 * bump).reshape(-1) * (1 + 0.01 * rng.standard_normal(cfg.N))
+    u = np.concatenate([rho, rho * 1.0])
+    h = 2.0
+    o = ko.Oracle(cfg)
+    un, err, wr, _ = o.rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
+    t, hn, st, rc = k.step(0.0, h, opts)
+    assert rel_l2(k.get_state(), un) < 1e-9
+    first = st.pc_used
+    k.set_state(u)
+    t, hn, st2, rc = k.step(0.0, h, opts)
+    assert rel_l2(k.get_state(), un) < 1e-9
+    if first & klib.PC_SPECTRAL and st.linear_its > 48:
+        assert not (st2.pc_used & klib.PC_SPECTRAL)          # it backed off
+    k.close()
