@@ -32,10 +32,10 @@ struct MGLevel {
 struct SpecState {
     bool ok = false, means_valid = false;
     KFFTPlan px, py;
-    int rb = 0, npair = 0;
+    int rb = 0, npair = 0, nyp = 0;
     size_t lds_rows = 0, lds_cols = 0;
     kcf *W = nullptr, *twx = nullptr, *twy = nullptr;
-    int *posx = nullptr, *posy = nullptr;
+    int *posx = nullptr, *posy = nullptr, *kyofpos = nullptr;
     float *lx = nullptr, *ly = nullptr;
     double a_rr = 0.0, a_rU[KSFD_MAXL] = { 0 };
     // adaptation: steps (counted by ksfd_step calls) before which the automatic choice leaves it alone after it converged badly

@@ -613,6 +613,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         bool spec_failed = false;
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
+            double bnorm2 = -1.0;                 // ||b||^2 when the RHS kernel's epilogue delivered it
             if (fuse_stage) {
                 // stage argument and Zdot term folded into the RHS kernel (no Z vector, no separate passes)
                 KComb cmb = KComb{};
@@ -621,7 +622,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                     if (h->Ginv[i][j] != 0.0) { cmb.yout[cmb.nout] = h->Y + (int64_t)j * vs; cmb.aout[cmb.nout++] = -h->Ginv[i][j] / hh; }
                 }
                 if (i > 0 && (rc = halo(h, h->Y + (int64_t)(i - 1) * vs))) break;     // ghosts of the newest stage vector (earlier ones done)
-                if ((rc = op_rhs(h, h->u, i, h->bvec, &cmb))) break;
+                if ((rc = op_rhs(h, h->u, i, h->bvec, &cmb, use_spec))) break;
+                if (use_spec) bnorm2 = h->hres[0];
             } else {
             if (i > 0) {
                 const double *xs[5]; double a[5]; int nt = 0;
@@ -643,10 +645,9 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             LinStats ls;
             if (use_spec) {
-                // a handful of iterations when it applies; cap the attempt so that a state it does not suit costs little
-                ksfd_step_opts so = *opts;
-                if (opts->pc_type == 2) so.ksp_max_it = 40;
-                rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, &so, &ls, 3, i);
+                // defect correction with M^-1 (no Krylov vectors), flexible GMRES for the rest if it contracts slowly; the attempt
+                // is capped so that a state it does not suit costs little, then the V cycle / plain GMRES takes over
+                rc = spec_solve(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, bnorm2, opts->pc_type == 2 ? 40 : 0);
                 st.pc_used |= 8;
                 if (rc == KSFD_ELINEAR && opts->pc_type == 2) {
                     spec_failed = true;

@@ -101,15 +101,27 @@ static KSrc src_of(const ksfd_handle *h, int stage)
 }
 
 // out = f(u) (+sources of `stage`); u must have valid ghosts when size>1
-static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr)
+// capacity of h->part in doubles (ksfd_create)
+static inline long long part_capacity() { return (long long)(2 * KSFD_MAXDOT + 4) * 4096; }
+
+// want_norm (fused 2-D path only): ||out||^2 lands in h->hres[0] without a pass of its own (per-wave partials in the store epilogue)
+static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr, bool want_norm = false)
 {
     const KGeom &G = h->G;
     KSrc S = src_of(h, stage);
     if (fused_ok(h)) {
         KStrips K = make_strips(h);
         KComb C = cmb ? *cmb : KComb{};
-        Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out, C));
+        const long long nwaves = (long long)K.nstrips * K.nseg;
+        const bool fused_norm = want_norm && nwaves <= part_capacity();
+        {
+            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr));
+        }
+        HIPCHK(h, hipGetLastError());
+        if (fused_norm) return reduce_rows(h, 1, (int)nwaves, 0);
+        if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm needs the strip kernels");
+        return KSFD_OK;
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -161,16 +173,23 @@ static int op_jcoef(ksfd_handle *h, const double *u)
 }
 
 // Jacobian action from the frozen coefficients (see stencil.hip.h, "Frozen-Jacobian path")
+// want_norm (fused 2-D path only): ||out||^2 -> h->hres[0]
 static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift, double *out,
-                         const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0)
+                         const double *yadd = nullptr, double alpha = 0.0, double beta = 0.0, bool want_norm = false)
 {
     const KGeom &G = h->G;
     const double nplanes = (3 + h->P.nlig) + 2.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0);   // coefficients + v + out (+ yadd)
     const double alg = 8.0 * (3.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc;   // read u, v, write out (+ the fused vector operand)
     if (fused_ok(h)) {
         KStrips K = make_strips(h, true);
-        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc, alg);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta));
+        const long long nwaves = (long long)K.nstrips * K.nseg;
+        if (want_norm && nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_jvp_frozen: too many waves for the fused norm");
+        {
+            Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc, alg);
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta, KSmooth{}, want_norm ? h->part : (double *)nullptr));
+        }
+        HIPCHK(h, hipGetLastError());
+        return want_norm ? reduce_rows(h, 1, (int)nwaves, 0) : KSFD_OK;
     } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {

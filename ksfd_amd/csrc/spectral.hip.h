@@ -188,65 +188,106 @@ __device__ __forceinline__ int kspec_tile(int b, int ntiles)
 }
 
 // rows of v (F fp64 planes, x fastest, no ghosts) -> W[pair][pos][y] ; blockIdx.y = pair
-__global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int ny, int rb, int ntiles, int F, const double *__restrict__ v, long long plane,
+__global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* column stride of W */, int rb, int ntiles, int F, const double *__restrict__ v, long long plane,
                                                         kcf *__restrict__ W, const kcf *__restrict__ tw)
 {
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
-    const int y0 = kspec_tile(blockIdx.x, ntiles) * rb;
+    const int y0 = kspec_tile(blockIdx.x, ntiles < 0 ? -ntiles : ntiles) * rb;
     const int sstride = nx + (nx >> 4) + 1;
     const double *va = v + (long long)(2 * p) * plane + (long long)y0 * nx;
     const bool has_b = 2 * p + 1 < F;
     const double *vb = has_b ? va + plane : va;
-    const int half = nx >> 1;
-    for (int idx = threadIdx.x; idx < rb * half; idx += blockDim.x) {
-        const int r = idx / half, x = 2 * (idx - r * half);
-        const double2 a = *reinterpret_cast<const double2 *>(va + (long long)r * nx + x);
-        double2 b = make_double2(0.0, 0.0);
-        if (has_b) b = *reinterpret_cast<const double2 *>(vb + (long long)r * nx + x);
-        kcf *row = kspec_lds + r * sstride;
-        row[kspec_pad(x)] = make_float2((float)a.x, (float)b.x);
-        row[kspec_pad(x + 1)] = make_float2((float)a.y, (float)b.y);
+    const int half = nx >> 1, lg_half = PX.lg - 1;
+    const int lg_rb = 31 - __clz(rb);             // rb is a power of two (spec_build)
+    // loads in batches of 4 items per thread, all issued before the first LDS store (one memory latency per batch, not per item)
+    for (int base = 0; base < rb * half; base += 4 * blockDim.x) {
+        double2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            a[u] = b[u] = make_double2(0.0, 0.0);
+            if (idx < rb * half) {
+                const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
+                a[u] = *reinterpret_cast<const double2 *>(va + (long long)r * nx + x);
+                if (has_b) b[u] = *reinterpret_cast<const double2 *>(vb + (long long)r * nx + x);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < rb * half) {
+                const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
+                kcf *row = kspec_lds + r * sstride;
+                row[kspec_pad(x)] = make_float2((float)a[u].x, (float)b[u].x);
+                row[kspec_pad(x + 1)] = make_float2((float)a[u].y, (float)b[u].y);
+            }
+        }
     }
     __syncthreads();
     kspec_fft_fwd(PX, kspec_lds, sstride, rb, tw);
-    kcf *Wp = W + (long long)p * nx * ny + y0;
+    if (ntiles < 0) {              // timing experiment only (KSFD_SPEC_DIAG bit 3): contiguous tile-major store
+        kcf *Wt = W + ((long long)p * (-ntiles) + y0 / rb) * nx * rb;
+        for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
+            const int j = idx >> lg_rb, r = idx & (rb - 1);
+            Wt[idx] = kspec_lds[r * sstride + kspec_pad(j)];
+        }
+        return;
+    }
+    kcf *Wp = W + (long long)p * nx * nyp + y0;
     for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
-        const int j = idx / rb, r = idx - j * rb;
-        Wp[(long long)j * ny + r] = kspec_lds[r * sstride + kspec_pad(j)];
+        const int j = idx >> lg_rb, r = idx & (rb - 1);
+        Wp[(long long)j * nyp + r] = kspec_lds[r * sstride + kspec_pad(j)];
     }
 }
 
 // W[pair][pos][y] -> rows of z (F fp64 planes)
-__global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int ny, int rb, int ntiles, int F, const kcf *__restrict__ W,
-                                                        double *__restrict__ z, long long plane, const kcf *__restrict__ tw)
+// xadd != NULL: z = xadd + M^-1 v (xadd may alias z: every element is read and written by the same thread)
+__global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, int rb, int ntiles, int F, const kcf *__restrict__ W,
+                                                        double *z, long long plane, const kcf *__restrict__ tw, const double *xadd)
 {
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
     const int y0 = kspec_tile(blockIdx.x, ntiles) * rb;
     const int sstride = nx + (nx >> 4) + 1;
-    const kcf *Wp = W + (long long)p * nx * ny + y0;
-    for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
-        const int j = idx / rb, r = idx - j * rb;
-        kspec_lds[r * sstride + kspec_pad(j)] = Wp[(long long)j * ny + r];
+    const kcf *Wp = W + (long long)p * nx * nyp + y0;
+    const int lg_rb = 31 - __clz(rb), lg_half = PX.lg - 1;
+    for (int base = 0; base < rb * nx; base += 8 * blockDim.x) {
+        kcf t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < rb * nx) { const int j = idx >> lg_rb, r = idx & (rb - 1); t[u] = Wp[(long long)j * nyp + r]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < rb * nx) { const int j = idx >> lg_rb, r = idx & (rb - 1); kspec_lds[r * sstride + kspec_pad(j)] = t[u]; }
+        }
     }
     __syncthreads();
     kspec_fft_inv(PX, kspec_lds, sstride, rb, tw);
-    double *za = z + (long long)(2 * p) * plane + (long long)y0 * nx;
     const bool has_b = 2 * p + 1 < F;
     const int half = nx >> 1;
     for (int idx = threadIdx.x; idx < rb * half; idx += blockDim.x) {
-        const int r = idx / half, x = 2 * (idx - r * half);
+        const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
         const kcf *row = kspec_lds + r * sstride;
         const kcf c0 = row[kspec_pad(x)], c1 = row[kspec_pad(x + 1)];
-        *reinterpret_cast<double2 *>(za + (long long)r * nx + x) = make_double2((double)c0.x, (double)c1.x);
-        if (has_b) *reinterpret_cast<double2 *>(za + plane + (long long)r * nx + x) = make_double2((double)c0.y, (double)c1.y);
+        const long long o = (long long)(2 * p) * plane + (long long)(y0 + r) * nx + x;
+        double2 a = make_double2((double)c0.x, (double)c1.x), b = make_double2((double)c0.y, (double)c1.y);
+        if (xadd) {
+            const double2 xa = *reinterpret_cast<const double2 *>(xadd + o);
+            a.x += xa.x; a.y += xa.y;
+            if (has_b) { const double2 xb = *reinterpret_cast<const double2 *>(xadd + o + plane); b.x += xb.x; b.y += xb.y; }
+        }
+        *reinterpret_cast<double2 *>(z + o) = a;
+        if (has_b) *reinterpret_cast<double2 *>(z + o + plane) = b;
     }
 }
 
 // one block per {kx, -kx}: forward FFT along y, symbol, inverse FFT along y, in place in W
-__global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int npair, int F, kcf *__restrict__ W, const kcf *__restrict__ tw,
-                                                   const int *__restrict__ posx, const int *__restrict__ posy,
+__global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp, int npair, int F, kcf *__restrict__ W, const kcf *__restrict__ tw,
+                                                   const int *__restrict__ posx, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
@@ -256,25 +297,40 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int npai
     const int jA = posx[kxA], jB = posx[kxB];
     const int sstride = ny + (ny >> 4) + 1;
     const int nseq = 2 * npair;
-    const int half = ny >> 1;
-    for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
-        const int s = idx / half, y = 2 * (idx - s * half);
-        const kcf *col = W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * ny;
-        const float4 t = *reinterpret_cast<const float4 *>(col + y);
-        kcf *q = kspec_lds + s * sstride;
-        q[kspec_pad(y)] = make_float2(t.x, t.y);
-        q[kspec_pad(y + 1)] = make_float2(t.z, t.w);
+    const int half = ny >> 1, lg_half = PY.lg - 1;
+    for (int base = 0; base < nseq * half; base += 8 * blockDim.x) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < nseq * half) {
+                const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
+                t[u] = *reinterpret_cast<const float4 *>(W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * nyp + y);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < nseq * half) {
+                const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
+                kcf *q = kspec_lds + s * sstride;
+                q[kspec_pad(y)] = make_float2(t[u].x, t[u].y);
+                q[kspec_pad(y + 1)] = make_float2(t[u].z, t[u].w);
+            }
+        }
     }
     __syncthreads();
     kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
-    // symbol stage.  item -> the pair of points k = (colA', ky), -k = (colB', -ky)
-    const int nitem = self ? 2 * (half + 1) : ny;
+    // symbol stage.  item -> the pair of points k = (colA', ky), -k = (colB', -ky), walked in POSITION order of ky so that
+    // both LDS accesses of a wave are consecutive (the partner positions of consecutive positions run consecutively backwards)
+    const int nitem = self ? 2 * ny : ny;
     for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
-        int ca, cb, ky;
-        if (self) { ca = cb = item / (half + 1); ky = item - ca * (half + 1); }
-        else { ca = 0; cb = 1; ky = item; }
-        const int kym = ky ? ny - ky : 0;
-        const int m = kspec_pad(posy[ky]), mp = kspec_pad(posy[kym]);
+        const int mpos = item & (ny - 1);
+        const int ky = kyofpos[mpos];
+        int ca = 0, cb = 1;
+        if (self) { ca = cb = item >> PY.lg; if (ky > half) continue; }      // (c, ky) and (c, -ky) are one item
+        const int kym = (ny - ky) & (ny - 1);
+        const int m = kspec_pad(mpos), mp = kspec_pad(posy[kym]);
         const float L2 = lx[ca ? kxB : kxA] + ly[ky];
         kcf vh[KSFD_MAXL + 2];
         for (int p = 0; p < npair; p++) {
@@ -289,13 +345,13 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int npai
         float invd[KSFD_MAXL];
         for (int l = 0; l < S.nlig; l++) {
             const float d = S.shift + S.gam[l] - S.D[l] * L2;
-            invd[l] = 1.0f / d;
+            invd[l] = __builtin_amdgcn_rcpf(d);
             const float c = S.a_rU[l] * L2 * invd[l];
             den -= c * S.s[l];
             num.x += c * vh[l + 1].x; num.y += c * vh[l + 1].y;
         }
         if (!(fabsf(den) >= S.den_floor)) den = den < 0.0f ? -S.den_floor : S.den_floor;
-        const float sc = S.scale / den;
+        const float sc = S.scale * __builtin_amdgcn_rcpf(den);
         kcf zh[KSFD_MAXL + 2];
         zh[0] = make_float2(num.x * sc, num.y * sc);
         for (int l = 0; l < S.nlig; l++) {
@@ -313,8 +369,8 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int npai
     __syncthreads();
     kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
-        const int s = idx / half, y = 2 * (idx - s * half);
-        kcf *col = W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * ny;
+        const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
+        kcf *col = W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * nyp;
         const kcf *q = kspec_lds + s * sstride;
         const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
         *reinterpret_cast<float4 *>(col + y) = make_float4(c0.x, c0.y, c1.x, c1.y);

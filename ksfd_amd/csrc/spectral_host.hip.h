@@ -30,7 +30,7 @@ static int spec_pos(const KFFTPlan &P, int k)
 static void spec_free(ksfd_handle *h)
 {
     SpecState &S = h->spec;
-    void *bufs[] = { S.W, S.twx, S.twy, S.posx, S.posy, S.lx, S.ly };
+    void *bufs[] = { S.W, S.twx, S.twy, S.posx, S.posy, S.kyofpos, S.lx, S.ly };
     for (void *b : bufs) if (b) hipFree(b);
     S = SpecState();
 }
@@ -57,6 +57,7 @@ static void spec_build(ksfd_handle *h)
     if (rb < 1) return;
     // rows per block: as many as the LDS holds (wider store segments of the transposed write), but keep >= 2 tiles per CU
     while (rb > 2 && G.ny / rb < 512) rb >>= 1;
+    if (getenv("KSFD_SPEC_RB")) rb = std::max(1, std::min(rb, atoi(getenv("KSFD_SPEC_RB"))));
     S.rb = rb;
     S.lds_rows = row_bytes * rb;
     S.lds_cols = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * 2 * S.npair;
@@ -70,14 +71,18 @@ static void spec_build(ksfd_handle *h)
         return t;
     };
     auto positions = [](const KFFTPlan &P) { std::vector<int> p(P.n); for (int k = 0; k < P.n; k++) p[k] = spec_pos(P, k); return p; };
+    auto inverse = [](const std::vector<int> &p) { std::vector<int> q(p.size()); for (size_t k = 0; k < p.size(); k++) q[p[k]] = (int)k; return q; };
     auto symbol = [](int n, double inv_h2) {
         std::vector<float> l(n);
         for (int k = 0; k < n; k++) { const double th = 2.0 * M_PI * k / n; l[k] = (float)((-30.0 + 32.0 * cos(th) - 2.0 * cos(2.0 * th)) / 12.0 * inv_h2); }
         return l;
     };
-    if (hipMalloc((void **)&S.W, sizeof(kcf) * (size_t)S.npair * G.nx * G.ny) != hipSuccess ||
+    // columns of W are padded by 256 B: with a power-of-two column stride every block of the column kernel (and every store
+    // segment of the transposed write) would walk the HBM channels in lockstep
+    S.nyp = (int)G.ny + (getenv("KSFD_SPEC_PAD") ? 32 : 0);      // (measured: a 256-B pad makes all three kernels ~5 % slower; no channel lockstep to break)
+    if (hipMalloc((void **)&S.W, sizeof(kcf) * (size_t)S.npair * G.nx * S.nyp) != hipSuccess ||
         !spec_upload(&S.twx, twiddles(S.px.n)) || !spec_upload(&S.twy, twiddles(S.py.n)) ||
-        !spec_upload(&S.posx, positions(S.px)) || !spec_upload(&S.posy, positions(S.py)) ||
+        !spec_upload(&S.posx, positions(S.px)) || !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) ||
         !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1]))) { hipGetLastError(); spec_free(h); return; }
     S.ok = true;
 }
@@ -103,7 +108,8 @@ static int spec_means(ksfd_handle *h)
 }
 
 // z = M^-1 v, M = shift*I - J0 (constant-coefficient part of the frozen Jacobian)
-static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z)
+// xadd != NULL: z = xadd + M^-1 v (one Richardson update without a vector pass of its own)
+static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, const double *xadd = nullptr)
 {
     SpecState &S = h->spec;
     const KGeom &G = h->G;
@@ -116,21 +122,29 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z)
     Y.den_floor = (float)(0.02 * shift);
     for (int l = 0; l < h->P.nlig; l++) { Y.a_rU[l] = (float)S.a_rU[l]; Y.s[l] = (float)h->P.lig_s[l]; Y.gam[l] = (float)h->P.lig_gamma[l]; Y.D[l] = (float)h->P.lig_D[l]; }
     const int ntiles = (int)(G.ny / S.rb);
-    const int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
-    const int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * S.npair * G.ny / 16));
+    // timing-only diagnostics (wrong results): KSFD_SPEC_DIAG bit0/1/2 = skip the FFT stages of the rows-fwd / cols / rows-inv kernel, bit3 = rows-fwd stores tile-major (contiguous)
+    static const int diag = getenv("KSFD_SPEC_DIAG") ? atoi(getenv("KSFD_SPEC_DIAG")) : 0;
+    KFFTPlan px_f = S.px, py_c = S.py, px_i = S.px;
+    if (diag & 1) px_f.nstage = 0;
+    if (diag & 2) py_c.nstage = 0;
+    if (diag & 4) px_i.nstage = 0;
+    int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
+    if (getenv("KSFD_SPEC_THRR")) thr_rows = atoi(getenv("KSFD_SPEC_THRR"));
+    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * S.npair * G.ny / 16));
+    if (getenv("KSFD_SPEC_THRC")) thr_cols = atoi(getenv("KSFD_SPEC_THRC"));
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
         Scope sc(h, KC_SPECTRAL, 8.0 * fn + pn, 8.0 * fn);                      // read v | write W
-        hipLaunchKernelGGL(k_spec_rows_fwd, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, S.px, (int)G.ny, S.rb, ntiles, G.F, v, G.plane, S.W, (const kcf *)S.twx);
+        hipLaunchKernelGGL(k_spec_rows_fwd, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v, G.plane, S.W, (const kcf *)S.twx);
     }
     {
         Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // W in place
-        hipLaunchKernelGGL(k_spec_cols, dim3((unsigned)(G.nx / 2)), dim3(thr_cols), S.lds_cols, h->st, S.py, (int)G.nx, S.npair, G.F, S.W, (const kcf *)S.twy,
-                           (const int *)S.posx, (const int *)S.posy, (const float *)S.lx, (const float *)S.ly, Y);
+        hipLaunchKernelGGL(k_spec_cols, dim3((unsigned)(G.nx / 2)), dim3(thr_cols), S.lds_cols, h->st, py_c, (int)G.nx, S.nyp, S.npair, G.F, S.W, (const kcf *)S.twy,
+                           (const int *)S.posx, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
     }
     {
-        Scope sc(h, KC_SPECTRAL, pn + 8.0 * fn, 8.0 * fn);                      // read W | write z
-        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, S.px, (int)G.ny, S.rb, ntiles, G.F, (const kcf *)S.W, z, G.plane, (const kcf *)S.twx);
+        Scope sc(h, KC_SPECTRAL, pn + (xadd ? 16.0 : 8.0) * fn, (xadd ? 16.0 : 8.0) * fn);     // read W (+ x) | write z
+        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)S.W, z, G.plane, (const kcf *)S.twx, xadd);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;

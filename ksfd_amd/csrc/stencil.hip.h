@@ -471,6 +471,7 @@ __device__ __forceinline__ void ksfd_dxx(double a0, double a1, const KX &x, doub
 }
 
 struct KWaveJob {
+    long long wid;      // logical wave id (strip + nstrips * segment slot of this launch)
     long long c0;       // first of this lane's two columns (wrapped)
     long long r0, r1;   // row segment [r0, r1)
     bool store;
@@ -485,6 +486,7 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
     KWaveJob J;
     const int lane = threadIdx.x & (KSFD_WAVE - 1);
     const long long wid = (long long)ksfd_xcd_remap(blockIdx.x, S.nblocks) * (KSFD_BLOCK / KSFD_WAVE) + (threadIdx.x >> 6);
+    J.wid = wid;
     J.valid = wid < (long long)S.nstrips * S.nseg;
     const int strip = (int)(wid % S.nstrips);
     const long long seg = S.seg0 + (wid / S.nstrips) * S.seg_stride;
@@ -504,10 +506,14 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
 
 template <int NL>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KStrips S, const double *__restrict__ u,
-                                                            KSrc src, double *__restrict__ out, KComb cmb = KComb{})
+                                                            KSrc src, double *__restrict__ out, KComb cmb = KComb{},
+                                                            double *__restrict__ normpart = nullptr)
 {
+    // normpart != NULL: every wave also leaves the sum of squares of what it stored in normpart[wave id] (||out||^2 without
+    // a pass of its own; finished by k_reduce_rows in a fixed order)
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;                       // whole waves only; the kernel has no block barrier
+    double nacc = 0.0;
     // 5-row windows, two columns per lane: slot s <-> row (r - 2 + s)
     double rw[5][2], gw[5][2], uw[NL][5][2];
     double nr[2], nu[NL][2];                   // raw values of the row being prefetched
@@ -600,8 +606,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
                     a += cmb.aout[j] * y.x; b += cmb.aout[j] * y.y;
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
+                nacc += a * a + b * b;
             }
         }
+    }
+    if (normpart) {
+        nacc = ksfd_wave_sum(nacc);
+        if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) normpart[J.wid] = nacc;
     }
 }
 
@@ -762,8 +773,10 @@ template <int NL, typename TC = double, typename TV = double, typename TY = doub
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const TC *__restrict__ C,
                                                              const TV *__restrict__ v, int mode, double shift,
                                                              TO *__restrict__ out, const TY *__restrict__ yadd = nullptr,
-                                                             double alpha = 0.0, double beta = 0.0, KSmooth sm = KSmooth{})
+                                                             double alpha = 0.0, double beta = 0.0, KSmooth sm = KSmooth{},
+                                                             double *__restrict__ normpart = nullptr)
 {
+    // normpart != NULL (modes 0-4): ||out||^2 partials per wave, see k_rhs2d_fused
     // mode 0: out = J v ; 1: out = shift*v - J v ; 2: out = yadd - (shift*v - J v)   (residual b - A x) ;
     // 3: out = alpha*yadd + beta*(shift*v - J v)   (one Horner step of the polynomial preconditioner) ;
     // 4: out = alpha*v + beta*(shift*v - J v)      (first Horner step: no extra plane is read)
@@ -771,6 +784,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
     if (!J.valid) return;
     double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
     double nr[PF][2], ng[PF][2], nq[PF][2], nv[PF][2], nc[PF][NL][2], nz[PF][NL][2];
+    double nacc = 0.0;
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, (PF > 1 ? 1 : 0)> B1;
 
@@ -913,6 +927,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
+                nacc += a * a + b * b;
             }
         }
     };
@@ -923,6 +938,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
             do_row(B0(), r);
             if (r + 1 < J.r1) do_row(B1(), r + 1);
         }
+    }
+    if (normpart) {
+        nacc = ksfd_wave_sum(nacc);
+        if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) normpart[J.wid] = nacc;
     }
 }
 

@@ -96,7 +96,7 @@ def test_step_with_spectral_preconditioner_vs_oracle_lu(shape, nlig, h, pc):
     k.set_state(u)
     t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-12, pc_type=pc))
     assert st.pc_used & klib.PC_SPECTRAL
-    assert st.linear_its <= 4 * 14, st.linear_its           # (to ksp_rtol 1e-12; ~3 per stage at the default 1e-6) a near-uniform state: few iterations at any h
+    assert st.linear_its <= 4 * 18, st.linear_its           # to ksp_rtol 1e-12 (~3-4 per stage at the default 1e-6): a near-uniform state needs few sweeps at any h
     assert rel_l2(k.get_state(), un) < 1e-10
     assert abs(st.wrms - wr) <= 1e-6 * wr
     k.close()

@@ -1,6 +1,7 @@
 """Spectral preconditioner: time per application (three kernels) and per-kernel split via the profile, 4096^2 by default."""
 import sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bench import build_problem
 from ksfd_amd import lib as klib
 from ksfd_amd.initial import start_values
