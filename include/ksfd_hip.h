@@ -85,7 +85,7 @@ typedef struct ksfd_dist {
 typedef struct ksfd_step_opts {
     double rtol, atol;          /* TSSetTolerances (KSFD/ksfdts.py:136) */
     int32_t adapt;              /* 1 = TSAdaptBasic, 0 = -ts_adapt_type none */
-    int32_t max_reject;         /* rejections tolerated inside one call (PETSc default 10); <0: single attempt */
+    int32_t max_reject;         /* rejections tolerated inside one call (PETSc default 10); < 0: unlimited (-ts_max_reject -1) */
     double clip_lo, clip_hi;    /* 0.1, 5 */
     double dt_min, dt_max;      /* 1e-20, 1e4 */
     double safety, reject_safety; /* 0.9, 0.5 */
@@ -95,7 +95,10 @@ typedef struct ksfd_step_opts {
                                  * (constant-coefficient part of shift*I - J inverted by FFT; 2-D, power-of-two grid, one rank) while
                                  * it converges in a few iterations, else multigrid when the step is stiff, Chebyshev polynomial +
                                  * flexible GMRES when mildly stiff, none when not; 3 polynomial only; 4 spectral always */
-    int32_t reserved;           /* 0: CGS2 with algebraic second projection (default); 1: classic two-pass CGS2 */
+    int32_t reserved;           /* flags.  bit 0: classic two-pass CGS2 instead of CGS2 with the algebraic second projection;
+                                 * bit 1: single attempt per call -- a rejected step returns with accepted = 0 and *hstep = the
+                                 * controller's proposal (callers that must refresh stage-time data per attempt);
+                                 * bit 2: the previous attempt of this step was rejected (TSAdaptBasic then applies reject_safety) */
 } ksfd_step_opts;
 
 typedef struct ksfd_step_stats {
@@ -131,7 +134,12 @@ int ksfd_rccl_unique_id(void *out128);
 int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_handle **out);
 void ksfd_destroy(ksfd_handle *h);
 const char *ksfd_last_error(const ksfd_handle *h);          /* h may be NULL: error of a failed create */
-int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg);   /* time-dependent ps.values(t) */
+int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg);   /* time-dependent ps.values(t): Jacobian / operators at t */
+/* Time-dependent parameters inside a step: the reference hands ps.values(t) at the STAGE time t_n + ASum_i*h to every RHS
+ * evaluation (KSFD/ksfdsym.py:1303-1312, 1430-1439 via implicitIF, KSFD/ksfdts.py:563-596) while the Jacobian uses
+ * ps.values(t_n).  stage 0..3 sets the table the i-th stage RHS of ksfd_step uses, -1 all four; cfg == NULL clears (the
+ * stages then use the ksfd_update_params table).  Grid and ligand count must match the handle's. */
+int ksfd_set_stage_params(ksfd_handle *h, int32_t stage, const ksfd_config *cfg);
 int ksfd_local_range(const ksfd_handle *h, int64_t *slow_begin, int64_t *slow_end); /* Grid._ranges on the slab axis */
 int64_t ksfd_local_size(const ksfd_handle *h);               /* F * local points: length of every host buffer */
 

@@ -50,6 +50,8 @@ struct ksfd_handle {
     double grp_alpha[KSFD_MAXL], grp_beta[KSFD_MAXL];
     KGeom G;
     KPhys P;
+    KPhys Pst[4];                    // ps.values(t_stage) for the four stage RHS evaluations (ksfd_set_stage_params)
+    bool Pst_valid[4] = { false, false, false, false };
     KVec kv;
     int rank = 0, size = 1, device = 0;
     int64_t slow0 = 0;               // first owned global slow index
@@ -75,6 +77,7 @@ struct ksfd_handle {
     double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes
     double *coef = nullptr;                 // frozen-Jacobian coefficient planes [rho, G, G_rho, G_U..]
     bool use_frozen = true;
+    bool coef_fresh = false;                // coef (and coef32) belong to the resident state u as it is now (ensure_coef)
     double *flat = nullptr;                 // staging for host layouts: max(F,dim)*nloc
     double *src[4][KSFD_MAXL + 1];          // dense source planes per stage (lazy)
     double *part = nullptr;                 // block partials
@@ -251,11 +254,11 @@ static void build_tableau(ksfd_handle *h)
     }
 }
 
-static int fill_phys(ksfd_handle *h, const ksfd_config *c)
+static int fill_phys(ksfd_handle *h, const ksfd_config *c, KPhys *dst = nullptr)
 {
     if (c->nlig < 1 || c->nlig > KSFD_MAXL || c->ngroups < 1 || c->ngroups > KSFD_MAXL)
         return fail(h, KSFD_EINVAL, "nlig=%d ngroups=%d outside 1..%d", c->nlig, c->ngroups, KSFD_MAXL);
-    KPhys &P = h->P;
+    KPhys &P = dst ? *dst : h->P;
     memset(&P, 0, sizeof P);
     P.nlig = c->nlig; P.ngroups = c->ngroups; P.cap_kind = c->cap_kind;
     for (int a = 0; a < 3; a++) {

@@ -303,7 +303,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
             const int k = j + 1;
-            if (o->reserved == 1) {
+            if (o->reserved & 1) {
                 // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
                 // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
                 if ((rc = op_multidot(h, w, V, k))) return rc;

@@ -205,7 +205,26 @@ extern "C" int ksfd_update_params(ksfd_handle *h, const ksfd_config *cfg)
     h->cfg = *cfg;
     h->cfg.lig_group = nullptr; h->cfg.lig_w = h->cfg.lig_s = h->cfg.lig_gamma = h->cfg.lig_D = nullptr;
     h->cfg.grp_alpha = h->cfg.grp_beta = nullptr;
+    h->coef_fresh = false;                                   // G, G_rho, G_U depend on the parameters
     return fill_phys(h, cfg);
+}
+
+extern "C" int ksfd_set_stage_params(ksfd_handle *h, int32_t stage, const ksfd_config *cfg)
+{
+    if (!h || stage < -1 || stage > 3) return KSFD_EINVAL;
+    if (!cfg) {                                            // clear: the stages use the handle's parameters again
+        for (int s = 0; s < 4; s++) if (stage == -1 || s == stage) h->Pst_valid[s] = false;
+        return KSFD_OK;
+    }
+    if (cfg->dim != h->cfg.dim || cfg->nlig != h->cfg.nlig) return fail(h, KSFD_EINVAL, "set_stage_params cannot change dim/nlig");
+    for (int a = 0; a < 3; a++) if (cfg->n[a] != h->cfg.n[a] || cfg->L[a] != h->cfg.L[a]) return fail(h, KSFD_EINVAL, "set_stage_params cannot change the grid");
+    for (int s = 0; s < 4; s++) {
+        if (stage != -1 && s != stage) continue;
+        int rc = fill_phys(h, cfg, &h->Pst[s]);
+        if (rc) return rc;
+        h->Pst_valid[s] = true;
+    }
+    return KSFD_OK;
 }
 
 extern "C" int ksfd_local_range(const ksfd_handle *h, int64_t *b, int64_t *e)
@@ -225,6 +244,7 @@ extern "C" int ksfd_set_state(ksfd_handle *h, const double *u, int32_t layout)
     if (!h || !u) return KSFD_EINVAL;
     hipSetDevice(h->device);
     int rc = upload(h, u, layout, h->u);
+    h->coef_fresh = false;
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->st));
     return KSFD_OK;
@@ -292,6 +312,7 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
     }
     if (!h->ckpt_valid) return fail(h, KSFD_EINVAL, "no checkpoint has been saved");
     HIPCHK(h, hipMemcpyAsync(h->u, h->ckpt, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
+    h->coef_fresh = false;
     const ksfd_handle::SolverMemo &m = h->ckpt_memo;
     h->lamJ = m.lamJ; h->lam_age = m.lam_age; h->lam_period = m.lam_period; h->mg_shift_floor = m.mg_shift_floor;
     h->sf_dir = m.sf_dir; h->sf_hold = m.sf_hold; h->sf_tried_down = m.sf_tried_down; h->sf_prev_its = m.sf_prev_its; h->sf_prev_floor = m.sf_prev_floor;
@@ -311,6 +332,7 @@ extern "C" int ksfd_set_state_random(ksfd_handle *h, const int64_t *nc, const do
         n *= nc[a];
     }
     double *dz = nullptr;
+    h->coef_fresh = false;
     if (hipMalloc((void **)&dz, sizeof(double) * (size_t)n) != hipSuccess) return fail(h, KSFD_ENOMEM, "hipMalloc of the coarse samples failed");
     hipError_t e = hipMemcpyAsync(dz, z, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->st);
     const KGeom &G = h->G;
@@ -375,8 +397,7 @@ extern "C" int ksfd_jvp(ksfd_handle *h, const double *uh, const double *vh, doub
     if ((rc = halo(h, uin)) || (rc = halo(h, h->t2))) return rc;
     if (!uh && h->use_frozen) {
         // the path the stepper uses: coefficients of the stored state once, then the frozen-coefficient kernels
-        if ((rc = op_jcoef(h, h->u))) return rc;
-        h->mg_coef_valid = false; h->mg_shift = -1.0;
+        if ((rc = ensure_coef(h, true))) return rc;
         if ((rc = op_jvp_frozen(h, h->t2, 0, 0.0, h->t3))) return rc;
     } else if ((rc = op_jvp(h, uin, h->t2, 0, 0.0, h->t3))) return rc;
     return download(h, h->t3, layout, outh);
@@ -386,16 +407,27 @@ static int velocity_common(ksfd_handle *h, const double *uin, double *vel_dev, d
 {
     const KGeom &G = h->G;
     int rc;
-    if ((rc = halo(h, (double *)uin))) return rc;
-    int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-    {
+    const double *Gplane = h->Gb;
+    if (uin == h->u && h->use_frozen) {
+        // the G plane of the resident state is plane 1 of the frozen coefficient planes; the next step reuses them
+        if ((rc = ensure_coef(h))) return rc;
+        Gplane = h->coef + G.plane;
+    } else {
+        if ((rc = halo(h, (double *)uin))) return rc;
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         Scope sc(h, KC_GFIELD, 8.0 * (G.F + 1) * (double)G.plane);
         NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, uin, (const double *)nullptr, h->Gb, (double *)nullptr));
     }
     int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 1024);
-    {
+    if (vmax && !vel_dev && G.dim == 2 && (G.nx % 2 == 0) && G.nx >= 4) {
+        // CFL check: max|dG/dx|, max|dG/dy| only -- row-structured kernel, 16-B loads, no 64-bit divisions
+        const int bx = (int)((G.nx / 2 + KSFD_BLOCK - 1) / KSFD_BLOCK), by = (int)std::min<long long>(G.sloc, std::max(1, 2048 / bx));
+        nb = bx * by;
+        Scope sc(h, KC_VELOCITY, 8.0 * (double)G.nloc);
+        hipLaunchKernelGGL(k_velmax2d, dim3(bx, by), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Gplane, h->part);
+    } else {
         Scope sc(h, KC_VELOCITY, 8.0 * (double)G.nloc * (1 + (vel_dev ? G.dim : 0)));
-        hipLaunchKernelGGL(k_velocity, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, h->Gb, vel_dev, vmax ? h->part : (double *)nullptr);
+        hipLaunchKernelGGL(k_velocity, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Gplane, vel_dev, vmax ? h->part : (double *)nullptr);
     }
     HIPCHK(h, hipGetLastError());
     if (vmax) {
@@ -455,6 +487,7 @@ extern "C" int ksfd_scale_rho(ksfd_handle *h, double factor)
 {
     if (!h) return KSFD_EINVAL;
     hipSetDevice(h->device);
+    h->coef_fresh = false;
     Scope sc(h, KC_MISC, 16.0 * (double)h->G.nloc);
     hipLaunchKernelGGL(k_mul_rho, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, (const double *)nullptr, factor);
     HIPCHK(h, hipGetLastError());
@@ -466,6 +499,7 @@ extern "C" int ksfd_mul_rho(ksfd_handle *h, const double *fh)
     if (!h || !fh) return KSFD_EINVAL;
     hipSetDevice(h->device);
     HIPCHK(h, hipMemcpyAsync(h->flat, fh, sizeof(double) * (size_t)h->G.nloc, hipMemcpyHostToDevice, h->st));
+    h->coef_fresh = false;
     Scope sc(h, KC_MISC, 24.0 * (double)h->G.nloc);
     hipLaunchKernelGGL(k_mul_rho, dim3(h->nblk_vec), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, (const double *)h->flat, 1.0);
     HIPCHK(h, hipGetLastError());
@@ -490,9 +524,7 @@ extern "C" int ksfd_jacobian_csr(ksfd_handle *h, int64_t *rowptr, int64_t *col, 
     int64_t nrows, nnz;
     ksfd_jacobian_nnz(h, &nrows, &nnz);
     int rc;
-    if ((rc = halo(h, h->u))) return rc;
-    if ((rc = op_jcoef(h, h->u))) return rc;                 // clamps like groom; the frozen planes are rebuilt by the next step anyway
-    h->mg_coef_valid = false; h->mg_shift = -1.0;
+    if ((rc = ensure_coef(h))) return rc;                    // clamps like groom
     long long *dcol = nullptr;
     double *dval = nullptr;
     if (hipMalloc((void **)&dcol, sizeof(long long) * (size_t)nnz) != hipSuccess ||
@@ -554,18 +586,17 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     int rc = KSFD_OK;
     const int64_t vs = h->vlen;
     double hh = *hstep;
-    bool prev_accept = true;
+    bool prev_accept = !(opts->reserved & 4);           // bit 2: the caller's previous attempt of this step was rejected
     bool lam_done = false;
     int rejects = 0;
-    const int max_rej = opts->max_reject;
+    const int max_rej = opts->max_reject < 0 ? 0x7fffffff : opts->max_reject;      // PETSc: -ts_max_reject -1 = unlimited
+    const bool single = (opts->reserved & 2) != 0;                                   // one attempt per call (the caller owns the reject loop)
     // KSFDTS.solve grooms the global vector before every TS.step (KSFD/ksfdts.py:210)
     if ((rc = ksfd_groom(h))) goto out;
     if ((rc = op_copy(h, h->usave, h->u))) goto out;
     if ((rc = halo(h, h->u))) goto out;
-    if (h->use_frozen && (rc = op_jcoef(h, h->u))) goto out;
-    h->mg_coef_valid = false; h->mg_shift = -1.0;
+    if (h->use_frozen && (rc = ensure_coef(h, true))) goto out;      // usually already there: the CFL check after the last step made them
     h->poly_shift = -1.0;
-    h->spec.means_valid = false;
     h->nsteps++;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
@@ -605,7 +636,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             use_poly = h->poly_deg >= 1 && h->poly_max_deg >= 1;
         }
         const bool small = (double)h->G.F * (double)h->G.nloc <= 6.0e6;
-        const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && opts->reserved == 0 && stiff >= 1e-3 &&
+        const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && !(opts->reserved & 1) && stiff >= 1e-3 &&
                                (h->size == 1 || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
         const bool fuse_stage = fused_ok(h) && h->P.nlig <= 4 && h->fuse_stage;
@@ -706,7 +737,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 } else { h->sf_dir = 0; h->sf_hold = 25; }
             }
         }
-        if (rc == KSFD_ELINEAR && opts->adapt && max_rej >= 0 && rejects < max_rej && hh * 0.25 >= opts->dt_min) {
+        if (rc == KSFD_ELINEAR && opts->adapt && !single && rejects < max_rej && hh * 0.25 >= opts->dt_min) {
             // PETSc's -ts_adapt_scale_solve_failed (0.25): a failed solve rejects the step and quarters it.  The
             // reference disables that by setMaxSNESFailures(1) (KSFD/ksfdts.py:135) because its LU cannot fail this
             // way; an iterative solve can, and aborting a long run for it would not be a service.
@@ -728,6 +759,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                                h->b2t[2] - h->bt[2], h->b2t[3] - h->bt[3], opts->atol, opts->rtol, h->errv, h->part);
         }
         h->have_err = true;
+        h->coef_fresh = false;                                   // u <- u_new (a rollback below makes the planes current again)
         if ((rc = reduce_rows(h, 1, h->nblk_vec, 0))) goto out;
         {
             double ntot = (double)h->G.F * (double)h->cfg.n[0] * (double)h->cfg.n[1] * (double)h->cfg.n[2];
@@ -735,6 +767,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         }
         if (!(st.wrms == st.wrms) || isinf(st.wrms)) {
             op_copy(h, h->u, h->usave); hipStreamSynchronize(h->st);
+            h->coef_fresh = h->use_frozen;
             rc = fail(h, KSFD_ENAN, "non-finite error norm at t=%g h=%g", *t, hh);
             goto out;
         }
@@ -761,9 +794,10 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         rejects++;
         st.rejections = rejects;
         if ((rc = op_copy(h, h->u, h->usave))) goto out;
+        h->coef_fresh = h->use_frozen;                           // the planes were made from exactly this state
         hh = hnext;
         *hstep = hnext;
-        if (max_rej < 0) break;                                  // single attempt: report the rejection
+        if (single) break;                                       // single attempt: report the rejection
         if (rejects > max_rej) { rc = fail(h, KSFD_EREJECT, "step rejected %d times at t=%g", rejects, *t); break; }
         if ((rc = halo(h, h->u))) goto out;
     }
@@ -829,8 +863,7 @@ extern "C" int ksfd_spectral_apply(ksfd_handle *h, double shift, const double *v
     if (!h->spec.ok) return fail(h, KSFD_EINVAL, "spectral preconditioner not available for this handle (needs 2-D, one rank, power-of-two extents)");
     int rc;
     if ((rc = upload(h, vh, layout, h->t2))) return rc;
-    if ((rc = halo(h, h->u)) || (rc = op_jcoef(h, h->u))) return rc;
-    h->mg_coef_valid = false; h->mg_shift = -1.0;
+    if ((rc = ensure_coef(h))) return rc;
     if ((rc = spec_means(h)) || (rc = spec_apply(h, shift, h->t2, h->t3))) return rc;
     return download(h, h->t3, layout, outh);
 }
@@ -900,7 +933,7 @@ extern "C" int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, doub
         return r;
     };
     if ((rc = halo(h, h->u))) goto done;
-    if (h->use_frozen && (cls == KC_JVP || cls == KC_SPECTRAL) && (rc = op_jcoef(h, h->u))) goto done;
+    if (h->use_frozen && (cls == KC_JVP || cls == KC_SPECTRAL) && (rc = ensure_coef(h, true))) goto done;
     if (cls == KC_SPECTRAL && (rc = spec_means(h))) goto done;
     for (int i = 0; i < 3 && !rc; i++) rc = one();
     if (rc) goto done;

@@ -109,6 +109,8 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
 {
     const KGeom &G = h->G;
     KSrc S = src_of(h, stage);
+    // time-dependent parameters: the reference evaluates ps.values(t) at the STAGE time of every RHS call
+    const KPhys &PP = (stage >= 0 && stage < 4 && h->Pst_valid[stage]) ? h->Pst[stage] : h->P;
     if (fused_ok(h)) {
         KStrips K = make_strips(h);
         KComb C = cmb ? *cmb : KComb{};
@@ -116,7 +118,7 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         const bool fused_norm = want_norm && nwaves <= part_capacity();
         {
             Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
-            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr));
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr));
         }
         HIPCHK(h, hipGetLastError());
         if (fused_norm) return reduce_rows(h, 1, (int)nwaves, 0);
@@ -126,11 +128,11 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
             Scope sc(h, KC_GFIELD, 8.0 * (G.F + 1) * (double)G.plane);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, (const double *)nullptr, h->Gb, (double *)nullptr));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_gfield<NL, false>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, PP, u, (const double *)nullptr, h->Gb, (double *)nullptr));
         }
         int nb = (int)std::min<long long>((G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         Scope sc(h, KC_RHS, vbytes(h, 2) + 8.0 * (double)G.nloc, vbytes(h, 2));
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_rhs_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->Gb, S, out));
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_rhs_generic<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, PP, u, h->Gb, S, out));
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
@@ -169,6 +171,21 @@ static int op_jcoef(ksfd_handle *h, const double *u)
     Scope sc(h, KC_GFIELD, (8.0 * (G.F + 3 + h->P.nlig) + (c32 ? 4.0 * (3 + h->P.nlig) : 0.0)) * (double)G.plane);
     NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef, c32));
     HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// Coefficient planes of the RESIDENT state, computed once per state: the CFL check after a step and the next step's
+// Jacobian need the same planes (the reference evaluates G twice there: velocity, KSFD/ksfdsym.py:1188-1209, and Jacobian).
+// coef_fresh is cleared by everything that changes h->u.
+static int ensure_coef(ksfd_handle *h, bool ghosts_done = false)
+{
+    if (h->coef_fresh) return KSFD_OK;
+    int rc;
+    if (!ghosts_done && (rc = halo(h, h->u))) return rc;
+    if ((rc = op_jcoef(h, h->u))) return rc;
+    h->coef_fresh = true;
+    h->mg_coef_valid = false; h->mg_shift = -1.0;
+    h->spec.means_valid = false;
     return KSFD_OK;
 }
 

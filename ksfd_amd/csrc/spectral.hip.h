@@ -286,11 +286,15 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
 }
 
 // one block per {kx, -kx}: forward FFT along y, symbol, inverse FFT along y, in place in W
-__global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp, int npair, int F, kcf *__restrict__ W, const kcf *__restrict__ tw,
+// (templated on the ligand count: the per-point arrays of the symbol stage must stay in registers -- with run-time loop
+//  bounds they went to scratch memory and the kernel took 126 us of pure data movement)
+template <int NL>
+__global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp, kcf *__restrict__ W, const kcf *__restrict__ tw,
                                                    const int *__restrict__ posx, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
     const int ny = PY.n, b = blockIdx.x;
     const bool self = b == 0;                                   // kx = 0 and kx = nx/2 are their own partners
     const int kxA = self ? 0 : b, kxB = self ? (nx >> 1) : nx - b;
@@ -332,7 +336,8 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp,
         const int kym = (ny - ky) & (ny - 1);
         const int m = kspec_pad(mpos), mp = kspec_pad(posy[kym]);
         const float L2 = lx[ca ? kxB : kxA] + ly[ky];
-        kcf vh[KSFD_MAXL + 2];
+        kcf vh[2 * npair];
+#pragma unroll
         for (int p = 0; p < npair; p++) {
             const kcf a = kspec_lds[(2 * p + ca) * sstride + m], bc = kc_conj(kspec_lds[(2 * p + cb) * sstride + mp]);
             const kcf su = kc_add(a, bc), di = kc_sub(a, bc);
@@ -342,8 +347,9 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp,
         // arrow-matrix solve with real multipliers
         float den = S.shift - S.a_rr * L2;
         kcf num = vh[0];
-        float invd[KSFD_MAXL];
-        for (int l = 0; l < S.nlig; l++) {
+        float invd[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
             const float d = S.shift + S.gam[l] - S.D[l] * L2;
             invd[l] = __builtin_amdgcn_rcpf(d);
             const float c = S.a_rU[l] * L2 * invd[l];
@@ -352,13 +358,15 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp,
         }
         if (!(fabsf(den) >= S.den_floor)) den = den < 0.0f ? -S.den_floor : S.den_floor;
         const float sc = S.scale * __builtin_amdgcn_rcpf(den);
-        kcf zh[KSFD_MAXL + 2];
+        kcf zh[2 * npair];
         zh[0] = make_float2(num.x * sc, num.y * sc);
-        for (int l = 0; l < S.nlig; l++) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
             // z_l = (v_l + s_l z_rho)/d_l with the 1/(nx ny) normalisation: z_rho already carries it
             zh[l + 1] = make_float2((vh[l + 1].x * S.scale + S.s[l] * zh[0].x) * invd[l], (vh[l + 1].y * S.scale + S.s[l] * zh[0].y) * invd[l]);
         }
         if (F & 1) zh[F] = make_float2(0.0f, 0.0f);
+#pragma unroll
         for (int p = 0; p < npair; p++) {
             const kcf za = zh[2 * p], zb = zh[2 * p + 1];
             // c_z(k) = z_a + i z_b ;  c_z(-k) = conj(z_a) + i conj(z_b)

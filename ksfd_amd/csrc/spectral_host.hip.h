@@ -64,7 +64,12 @@ static void spec_build(ksfd_handle *h)
     if (S.lds_cols > lds_max - 1024) return;
     if (hipFuncSetAttribute((const void *)k_spec_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_spec_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols) != hipSuccess) { hipGetLastError(); return; }
+        0) { hipGetLastError(); return; }
+    {
+        hipError_t e = hipSuccess;
+        NL_DISPATCH(h->P.nlig, e = hipFuncSetAttribute((const void *)k_spec_cols<NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols));
+        if (e != hipSuccess) { hipGetLastError(); return; }
+    }
     auto twiddles = [](int n) {
         std::vector<kcf> t(n);
         for (int k = 0; k < n; k++) { const double a = -2.0 * M_PI * k / n; t[k] = make_float2((float)cos(a), (float)sin(a)); }
@@ -139,8 +144,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     }
     {
         Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // W in place
-        hipLaunchKernelGGL(k_spec_cols, dim3((unsigned)(G.nx / 2)), dim3(thr_cols), S.lds_cols, h->st, py_c, (int)G.nx, S.nyp, S.npair, G.F, S.W, (const kcf *)S.twy,
-                           (const int *)S.posx, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec_cols<NL>), dim3((unsigned)(G.nx / 2)), dim3(thr_cols), S.lds_cols, h->st, py_c, (int)G.nx, S.nyp, S.W, (const kcf *)S.twy,
+                           (const int *)S.posx, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y));
     }
     {
         Scope sc(h, KC_SPECTRAL, pn + (xadd ? 16.0 : 8.0) * fn, (xadd ? 16.0 : 8.0) * fn);     // read W (+ x) | write z

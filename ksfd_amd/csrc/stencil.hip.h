@@ -713,6 +713,38 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_fused(KGeom G, KPhys P, KS
     }
 }
 
+// CFL check on a 2-D grid (KSFDTS.CFL_step, KSFD/ksfdts.py:302-319): per-axis max |D1(G)| only.  One thread per pair of
+// columns, rows by blockIdx.y; the x-neighbours are two more 16-B loads (L1 hits), the y-neighbours four.
+__global__ void __launch_bounds__(KSFD_BLOCK) k_velmax2d(KGeom G, KPhys P, const double *__restrict__ Gb, double *__restrict__ part)
+{
+    __shared__ double red[KSFD_BLOCK / KSFD_WAVE][2];
+    double mx = 0.0, my = 0.0;
+    const long long half = G.nx >> 1;
+    const long long pc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pc < half) {
+        const long long x = 2 * pc;
+        const long long xl = x >= 2 ? x - 2 : G.nx - 2, xr = x + 2 < G.nx ? x + 2 : 0;
+        for (long long r = blockIdx.y; r < G.sloc; r += gridDim.y) {
+            const double *row = Gb + ksfd_rowoff(G, r);
+            const double2 c = ksfd_ld2(row + x), l = ksfd_ld2(row + xl), rr = ksfd_ld2(row + xr);
+            const double2 m2 = ksfd_ld2(Gb + ksfd_rowoff(G, r - 2) + x), m1 = ksfd_ld2(Gb + ksfd_rowoff(G, r - 1) + x),
+                          p1 = ksfd_ld2(Gb + ksfd_rowoff(G, r + 1) + x), p2 = ksfd_ld2(Gb + ksfd_rowoff(G, r + 2) + x);
+            mx = fmax(mx, fmax(fabs(KSFD_D1(l.x, l.y, c.y, rr.x)), fabs(KSFD_D1(l.y, c.x, rr.x, rr.y))));
+            my = fmax(my, fmax(fabs(KSFD_D1(m2.x, m1.x, p1.x, p2.x)), fabs(KSFD_D1(m2.y, m1.y, p1.y, p2.y))));
+        }
+    }
+    mx = ksfd_wave_max(mx * P.inv_h[0]);
+    my = ksfd_wave_max(my * P.inv_h[1]);
+    if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) { red[threadIdx.x / KSFD_WAVE][0] = mx; red[threadIdx.x / KSFD_WAVE][1] = my; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double m = 0.0;
+        if (threadIdx.x < 2) for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) m = fmax(m, red[q][threadIdx.x]);
+        const long long nb = (long long)gridDim.x * gridDim.y;
+        part[(long long)threadIdx.x * nb + (long long)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Frozen-Jacobian path.  The Rosenbrock-W step keeps J = df/du(t_n, u_n) for all four stages and
 // every GMRES iteration (~40 Jacobian actions per step), so everything in J that depends only on

@@ -64,7 +64,7 @@ _lib = None
 
 # every symbol include/ksfd_hip.h declares (checked by tests/test_abi.py without a GPU)
 ABI_SYMBOLS = [
-    'ksfd_kernel_class_name', 'ksfd_rccl_unique_id', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params',
+    'ksfd_kernel_class_name', 'ksfd_rccl_unique_id', 'ksfd_create', 'ksfd_destroy', 'ksfd_last_error', 'ksfd_update_params', 'ksfd_set_stage_params',
     'ksfd_local_range', 'ksfd_local_size', 'ksfd_set_state', 'ksfd_get_state', 'ksfd_device_state',
     'ksfd_device_plane_stride', 'ksfd_device_interior_offset', 'ksfd_set_source', 'ksfd_rhs', 'ksfd_jvp',
     'ksfd_velocity', 'ksfd_velocity_max', 'ksfd_groom', 'ksfd_count_worms', 'ksfd_scale_rho', 'ksfd_mul_rho', 'ksfd_jacobian_nnz', 'ksfd_jacobian_csr', 'ksfd_set_state_random', 'ksfd_snapshot_begin', 'ksfd_snapshot_wait', 'ksfd_checkpoint',
@@ -93,6 +93,7 @@ def load():
     L.ksfd_last_error.argtypes = [vp]
     L.ksfd_last_error.restype = C.c_char_p
     L.ksfd_update_params.argtypes = [vp, C.POINTER(CConfig)]
+    L.ksfd_set_stage_params.argtypes = [vp, C.c_int32, C.POINTER(CConfig)]
     L.ksfd_local_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ksfd_local_size.argtypes = [vp]
     L.ksfd_local_size.restype = C.c_int64
@@ -213,6 +214,14 @@ class KSFDHip:
         self.cfg = cfg
         self._ccfg = cfg.as_ctypes()
         self._chk(self.L.ksfd_update_params(self.h, C.byref(self._ccfg)))
+
+    def set_stage_params(self, stage, cfg=None):
+        """ps.values(t_stage) for the stage-th RHS evaluation of the next steps (None clears; stage -1 = all four)"""
+        if cfg is None:
+            self._chk(self.L.ksfd_set_stage_params(self.h, int(stage), None))
+        else:
+            c = cfg.as_ctypes()
+            self._chk(self.L.ksfd_set_stage_params(self.h, int(stage), C.byref(c)))
 
     def set_source(self, field, src, stage=-1):
         if src is None:

@@ -107,6 +107,12 @@ def main(*args):
             t_start = t_last
             if 'dt' not in ps.given and 'dt' in info:
                 dt0 = float(info['dt'])
+            # time of the last variance injection (resume_values, ksfdsolver2.py:554-561): explicit parameter, else what the
+            # series recorded, else the resume time -- so that a resumed run injects noise when the uninterrupted one would
+            if 'lastvart' not in ps.given:
+                ps.params0['lastvart'] = float(info['lastvart']) if 'lastvart' in info else t_last
+        elif 'lastvart' not in ps.given:
+            ps.params0['lastvart'] = ps.t0                       # --restart: ksfdsolver2.py:562-567
     else:
         u0 = start_values(ps, cfg, rng)
         derivs.ks.set_state(local_slab(u0, cfg, rk.rank, rk.size) if rk.size > 1 else u0, SOA)

@@ -255,31 +255,53 @@ class KSFDTS:
     def setFromOptions(self):
         pass
 
-    def _refresh_time_dependent_params(self):
-        """Parameters may be sympy expressions of t (ksfdsolver2.py:149-173); the reference hands ps.values(t) to its
-        ufuncs on every call.  Here the numeric table is re-sent once per step, evaluated at the step's start time."""
+    ASUM = (0.0, 8.7173304301691801e-01, 8.4457060015369423e-01 - 1.1299064236484185e-01, 1.0)     # stage abscissae of RA34PW2
+
+    def _time_dependent(self):
+        """names of PDE coefficients that are expressions of t (ksfdsolver2.py:149-173); usually none"""
         ps = self.derivs.ps
         if not hasattr(ps, 'time_dependent') or not hasattr(ps, 'problem_config'):
-            return
+            return []
         if not hasattr(self, '_td'):
             self._td = [k for k in ps.time_dependent() if k not in ('variance_timing_function', 't')]
-        if self._td:
-            self.ks.update_params(ps.problem_config(self._t))
+        return self._td
+
+    def _refresh_time_dependent_params(self, h):
+        """The reference hands ps.values(t) to its ufuncs on every call: the Jacobian sees t_n (implicitIJ, KSFD/ksfdts.py:
+        598-640), each stage RHS its own stage time t_n + ASum_i h (implicitIF, :563-596; KSFD/ksfdsym.py:1303-1312,
+        1430-1439).  One small table per stage crosses the ABI (ksfd_update_params / ksfd_set_stage_params)."""
+        ps = self.derivs.ps
+        self.ks.update_params(ps.problem_config(self._t))
+        for i, a in enumerate(self.ASUM):
+            self.ks.set_stage_params(i, ps.problem_config(self._t + a * h))
 
     # ---- one TS.step(): replaces super().step() at KSFD/ksfdts.py:211
     def step(self):
         d = self.derivs
-        self._refresh_time_dependent_params()
-        if d.has_sources():
-            # time-dependent sources need the stage times t + ASum_i*h of THIS attempt: one attempt per call
-            asum = (0.0, 8.7173304301691801e-01, 8.4457060015369423e-01 - 1.1299064236484185e-01, 1.0)
-            self.opts.max_reject = -1
-            for _ in range(12):
-                d.upload_sources([self._t + a * self._h for a in asum])
+        tdep = bool(self._time_dependent())
+        if d.has_sources() or tdep:
+            # stage-time data (sources, time-dependent coefficients) belong to the stage times t + ASum_i*h of THIS attempt:
+            # one attempt per call (opts.reserved bit 1), the reject loop runs here; bit 2 carries "previous attempt rejected"
+            base = self.opts.reserved & 1
+            prev_rejected = False
+            limit = self.opts.max_reject if self.opts.max_reject >= 0 else 1 << 30
+            rejections = 0
+            while True:
+                if tdep:
+                    self._refresh_time_dependent_params(self._h)
+                if d.has_sources():
+                    d.upload_sources([self._t + a * self._h for a in self.ASUM])
+                self.opts.reserved = base | 2 | (4 if prev_rejected else 0)
                 t, h, st, rc = self.ks.step(self._t, self._h, self.opts, raise_on_error=False)
                 self._h = h
                 if rc or st.accepted:
                     break
+                prev_rejected = True
+                rejections += 1
+                if rejections > limit:
+                    break
+            self.opts.reserved = base
+            st.rejections = rejections
         else:
             t, h, st, rc = self.ks.step(self._t, self._h, self.opts, raise_on_error=False)
         self.last_stats = st
@@ -309,7 +331,7 @@ class KSFDTS:
         t = self.getTime()
         Nworms = self.count_worms(u)
         p0 = self.derivs.ps.params0
-        self.lastvart = p0['lastvart'] if 'lastvart' in getattr(self.derivs.ps, 'given', {}) else t
+        self.lastvart = float(p0['lastvart']) if 'lastvart' in p0 else t        # KSFD/ksfdts.py:193-196 (solver.main sets it on --resume/--restart)
         cw = p0.get('conserve_worms', False)
         conserve_worms = False if cw == 'False' else bool(cw)
         self.monitor(k, t, u)
@@ -425,6 +447,10 @@ class KSFDTS:
             self.timeseries.store(u, t, k=k)
             if hasattr(self.timeseries, 'set_dt'):
                 self.timeseries.set_dt(float(ts.getTimeStep()))
+            if hasattr(self.timeseries, 'info'):
+                # (superset of the reference, whose save monitor records dt only and leaves lastvart to the checkpoint monitor,
+                #  KSFD/ksfdts.py:420-422: with it a run resumed from a --save series injects noise on schedule too)
+                self.timeseries.info['lastvart'] = float(getattr(self, 'lastvart', t))
             if hasattr(self.timeseries, 'temp_close'):
                 self.timeseries.temp_close()
 

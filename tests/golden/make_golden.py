@@ -96,10 +96,43 @@ def build(dim, n, L, lig, cap='tophat', extra=(), source=()):
     return ps, g, d
 
 
-def meta_of(ps, g, cap):
-    v = ps.values0
+def fval(ps, x, t):
+    """number behind a parameter: constants are plain numbers, time-dependent ones stay sympy symbols whose value the
+    reference takes from ps.values(t) on every ufunc call (KSFD/ksfdsym.py:1303-1312, 1430-1439)"""
+    try:
+        return float(x)
+    except TypeError:
+        import sympy
+        return float(sympy.sympify(x).subs({sympy.Symbol(k): val for k, val in ps.values(t).items()}))
+
+
+def tables_at(ps, t):
+    """the numeric ligand / group tables the operators see at time t"""
     ligs = list(ps.Vgroups.ligands())
     groups = ps.Vgroups.groups
+    v = ps.values(t)
+    return dict(
+        s2=np.float64(v['s2']), rhomax=np.float64(v['rhomax']), cushion=np.float64(v['cushion']), maxscale=np.float64(v['maxscale']),
+        lig_w=np.array([fval(ps, l.weight, t) for l in ligs]), lig_s=np.array([fval(ps, l.s, t) for l in ligs]),
+        lig_gamma=np.array([fval(ps, l.gamma, t) for l in ligs]), lig_D=np.array([fval(ps, l.D, t) for l in ligs]),
+        grp_alpha=np.array([fval(ps, gr.alpha, t) for gr in groups]), grp_beta=np.array([fval(ps, gr.beta, t) for gr in groups]))
+
+
+def meta_of(ps, g, cap, t=None):
+    v = ps.values0 if t is None else ps.values(t)
+    ligs = list(ps.Vgroups.ligands())
+    groups = ps.Vgroups.groups
+    if t is not None:
+        tb = tables_at(ps, t)
+        n3 = [1, 1, 1]
+        L3 = [1.0, 1.0, 1.0]
+        for dd in range(g.dim):
+            n3[dd] = int(g.nps[dd])
+            L3[dd] = float(g.bounds[dd])
+        return dict(tb, dim=np.int64(g.dim), n=np.array(n3, dtype=np.int64), L=np.array(L3), nlig=np.int64(len(ligs)),
+                    ngroups=np.int64(len(groups)), cap_kind=np.int64(1 if cap == 'witch' else 0),
+                    rhomin=np.float64(v['rhomin']), Umin=np.float64(v['Umin']),
+                    lig_group=np.array([l.groupnum - 1 for l in ligs], dtype=np.int32))
     n3 = [1, 1, 1]
     L3 = [1.0, 1.0, 1.0]
     for dd in range(g.dim):
@@ -308,7 +341,7 @@ def operator_case(name, dim, n, L, lig, cap, seed, witch_near_cap=False):
 
 
 def step_case(name, dim, n, L, lig, cap, seed, h, nsteps, atol=0.01, rtol=1e-6, amp=90.0,
-              source=(), extra=(), u0_fn=None, t0=0.0):
+              source=(), extra=(), u0_fn=None, t0=0.0, time_dependent=False):
     tt = time.time()
     ps, g, d = build(dim, n, L, lig, cap, extra=extra, source=source)
     F = ps.nligands + 1
@@ -318,13 +351,14 @@ def step_case(name, dim, n, L, lig, cap, seed, h, nsteps, atol=0.01, rtol=1e-6, 
         u = seeded_state(rng, F, S, amp=amp)
         ligs = list(ps.Vgroups.ligands())
         for l, lg in enumerate(ligs):       # U = rho*s/gamma + small perturbation (ksfdsolver2.py:636-637)
-            u[l + 1] = u[0] * float(lg.s / lg.gamma) + 0.1 * amp * rng.standard_normal(S)
+            u[l + 1] = u[0] * fval(ps, lg.s / lg.gamma, t0) + 0.1 * amp * rng.standard_normal(S)
     else:
         u = u0_fn(g)
-    out = meta_of(ps, g, cap)
+    out = meta_of(ps, g, cap, t=t0 if time_dependent else None)
     out['u0'] = u.copy()
     out['h'] = np.float64(h)
     out['t0'] = np.float64(t0)
+    stage_tab = []
     out['atol'] = np.float64(atol)
     out['rtol'] = np.float64(rtol)
     out['nsteps'] = np.int64(nsteps)
@@ -340,6 +374,8 @@ def step_case(name, dim, n, L, lig, cap, seed, h, nsteps, atol=0.01, rtol=1e-6, 
                 ts_ = t + asum[i] * h
                 src_t.append(ts_)
                 src_v.append(np.stack([np.broadcast_to(d.sources[c](ts_), S) + 0.0 for c in range(F)]))
+        if time_dependent:          # what ps.values() hands the ufuncs: at t_n for the Jacobian, at the stage times for the RHS
+            stage_tab.append([tables_at(ps, t)] + [tables_at(ps, t + a * h) for a in RA_A.sum(axis=1)])
         unew, err, wrms = rosw_step(d, u, t, h, atol, rtol)
         if k == 0:
             out['u1'] = unew.copy()
@@ -349,6 +385,9 @@ def step_case(name, dim, n, L, lig, cap, seed, h, nsteps, atol=0.01, rtol=1e-6, 
         t += h
     out['uN'] = u
     out['wrms'] = np.array(wr)
+    if time_dependent:
+        for key in stage_tab[0][0]:        # (nsteps, 5, ...): index 0 = step start (Jacobian), 1..4 = the four stage times
+            out['tdep_' + key] = np.array([[tb[key] for tb in row] for row in stage_tab])
     if has_src:
         out['src_t'] = np.array(src_t)
         out['src_v'] = np.stack(src_v)          # (4*nsteps, F, *S): source fields at every stage time
@@ -531,6 +570,15 @@ def step_2d_n1_witch_cap():
 @case
 def step_2d_g2():
     step_case('step_2d_g2', 2, [12, 16], [0.04, 0.05], LIG_G2, 'tophat', 42, h=0.1, nsteps=4)
+
+
+@case
+def step_2d_n1_tdep():
+    """time-dependent coefficients: s_1_1 and beta_1 are expressions of t, so every RHS evaluation sees ps.values(t_stage)
+    and the Jacobian ps.values(t_n) (KSFD/ksfdsym.py:1303-1312, 1430-1439; KSFD/ksfdts.py:563-640)"""
+    lig = ['ngroups=1', 'nligands_1=1', 'alpha_1=1500', 'beta_1=5.56e-4*(1+0.3*t)', 's_1_1=0.01*(1+0.8*t)',
+           'gamma_1_1=0.01', 'D_1_1=1e-6', 'U0_1_1=9000.0']
+    step_case('step_2d_n1_tdep', 2, [20, 16], [0.06, 0.05], lig, 'tophat', 31, h=0.1, nsteps=3, t0=0.5, time_dependent=True)
 
 
 @case

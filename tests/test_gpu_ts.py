@@ -137,28 +137,69 @@ def test_resume_continues_a_saved_run(tmp_path):
     ts2.cleanup()
 
 
-def test_time_dependent_parameter_is_resent_each_step():
+def _tdep_cfg(z, k, i):
+    """ProblemConfig with the tables the reference's ps.values() held at step k: i = 0 step start, 1..4 the stage times"""
+    from ksfd_amd.config import ProblemConfig
+    return ProblemConfig(dim=int(z['dim']), n=tuple(int(x) for x in z['n']), L=tuple(float(x) for x in z['L']),
+                         lig_group=z['lig_group'], lig_w=z['tdep_lig_w'][k, i], lig_s=z['tdep_lig_s'][k, i],
+                         lig_gamma=z['tdep_lig_gamma'][k, i], lig_D=z['tdep_lig_D'][k, i], grp_alpha=z['tdep_grp_alpha'][k, i],
+                         grp_beta=z['tdep_grp_beta'][k, i], s2=float(z['tdep_s2'][k, i]), rhomax=float(z['tdep_rhomax'][k, i]),
+                         cushion=float(z['tdep_cushion'][k, i]), maxscale=float(z['tdep_maxscale'][k, i]),
+                         rhomin=float(z['rhomin']), Umin=float(z['Umin']), cap_kind=int(z['cap_kind']))
+
+
+def test_stage_time_parameters_vs_reference_golden():
+    """step_2d_n1_tdep.npz: s_1_1 and beta_1 are expressions of t; the reference's ufuncs receive ps.values(t) at every call,
+    i.e. the stage RHS sees t_n + ASum_i h and the Jacobian t_n (KSFD/ksfdsym.py:1303-1312, 1430-1439).  Library level:
+    the golden's own per-stage tables through ksfd_update_params / ksfd_set_stage_params."""
+    from conftest import load_golden
+    from ksfd_amd import lib as klib
+    z = load_golden('step_2d_n1_tdep')
+    k = klib.KSFDHip(_tdep_cfg(z, 0, 0))
+    k.set_state(cijk_to_soa(z['u0']))
+    t, h = float(z['t0']), float(z['h'])
+    opts = klib.default_step_opts(adapt=0, atol=float(z['atol']), rtol=float(z['rtol']), ksp_rtol=1e-12)
+    for s in range(int(z['nsteps'])):
+        k.update_params(_tdep_cfg(z, s, 0))
+        for i in range(4):
+            k.set_stage_params(i, _tdep_cfg(z, s, i + 1))
+        t, hn, st, rc = k.step(t, h, opts)
+        assert abs(st.wrms - z['wrms'][s]) <= 1e-6 * z['wrms'][s]
+        if s == 0:
+            assert rel_l2(k.get_state(), cijk_to_soa(z['u1'])) < 1e-10
+    assert rel_l2(k.get_state(), cijk_to_soa(z['uN'])) < 1e-10
+    # and the difference matters: the same steps with the step-start table at every stage miss by far more
+    k.set_state(cijk_to_soa(z['u0']))
+    k.set_stage_params(-1, None)
+    t = float(z['t0'])
+    for s in range(int(z['nsteps'])):
+        k.update_params(_tdep_cfg(z, s, 0))
+        t, hn, st, rc = k.step(t, h, opts)
+    assert rel_l2(k.get_state(), cijk_to_soa(z['uN'])) > 1e-7
+    k.close()
+
+
+def test_time_dependent_parameters_through_the_ts_loop():
+    """the same golden through the @options front end: expressions of t on the command line -> ps.problem_config(t) at the
+    stage times inside KSFDTS.step"""
+    from conftest import load_golden
     from ksfd_amd.ts import Derivatives, implicitTS
-    ns = opt.parse_commandline(['dim=1', 'nelements=64', 'width=0.05', 'sigma=0.02357', 's2=sigma**2/2*(1+10*t)',
-                                'alpha_1=1500', 'beta_1=5.56e-4', 's_1_1=0.01', 'gamma_1_1=0.01', 'D_1_1=1e-6',
-                                'dt=0.01', 'maxsteps=3', 'atol=0.01', 'rtol=1e-6', '--petsc', '-ts_adapt_type', 'none', '--'])
+    z = load_golden('step_2d_n1_tdep')
+    ns = opt.parse_commandline(['dim=2', 'nwidth=20', 'nheight=16', 'width=0.06', 'height=0.05', 'sigma=0.02357', 's2=sigma**2/2',
+                                'rhomax=28000', 'cushion=2000', 'rhomin=1e-7', 'Umin=1e-7', 'ngroups=1', 'nligands_1=1',
+                                'alpha_1=1500', 'beta_1=5.56e-4*(1+0.3*t)', 's_1_1=0.01*(1+0.8*t)', 'gamma_1_1=0.01', 'D_1_1=1e-6',
+                                't0=0.5', 'dt=0.1', 'maxsteps=3', 'atol=0.01', 'rtol=1e-6', '--petsc', '-ts_adapt_type', 'none', '--'])
     ps = opt.Params(ns)
-    cfg = ps.problem_config()
-    d = Derivatives(ps, cfg)
-    rho = 9000 + 90 * np.random.default_rng(0).standard_normal(64)
-    u0 = np.concatenate([rho, rho])
-    d.ks.set_state(u0)
-    ts = implicitTS(d, t0=0.0, dt=0.01, tmax=1.0, maxsteps=3, rtol=1e-6, atol=0.01, opts=opt.step_opts_from(ps, ns.petsc))
+    assert set(ps.time_dependent()) >= {'beta_1', 's_1_1'}
+    d = Derivatives(ps, ps.problem_config(0.5))
+    d.ks.set_state(cijk_to_soa(z['u0']))
+    ts = implicitTS(d, t0=0.5, dt=0.1, tmax=10.0, maxsteps=3, rtol=1e-6, atol=0.01, opts=opt.step_opts_from(ps, ns.petsc))
     ts.opts.ksp_rtol = 1e-12
     ts.solve()
     got = d.ks.get_state()
     ts.cleanup()
-    # the same three steps with the oracle, s2 evaluated at each step's start time
-    from oracle import ko
-    u = u0
-    for k in range(3):
-        u, _, _, _ = ko.Oracle(ps.problem_config(0.01 * k)).rosw_step(u, 0.01, 0.01, 1e-6, solver='lu')
-    assert rel_l2(got, u) < 1e-10
+    assert abs(ts.getTime() - 0.8) < 1e-12
+    assert rel_l2(got, cijk_to_soa(z['uN'])) < 1e-10
 
 
 def test_async_and_decimated_save_equal_the_synchronous_series(tmp_path):
@@ -236,3 +277,33 @@ def test_noise_injection_vs_the_references_own_methods():
     assert rel_l2(d.ks.get_state(PETSC), z['u_cons']) < 1e-14
     assert [bool(ts.is_noise_time(a, b)) for a, b in z['times']] == [bool(f) for f in z['fire']]
     ts.cleanup()
+
+
+def test_resume_restores_the_time_of_the_last_noise_injection(tmp_path, monkeypatch):
+    """--resume must take lastvart from the series (/info/lastvart; resume_values, ksfdsolver2.py:554-561): the resumed run
+    then injects noise at the times, and with the dt, an uninterrupted run does (sd = sqrt(variance_rate*dt))."""
+    from ksfd_amd import solver
+    from ksfd_amd import ts as tsmod
+    log = []
+    orig = tsmod.KSFDTS.add_variance
+
+    def spy(self, u, dt):
+        log.append((round(self.getTime(), 12), round(dt, 12)))
+        return orig(self, u, dt)
+    monkeypatch.setattr(tsmod.KSFDTS, 'add_variance', spy)
+    base = ['dim=2', 'nelements=32', 'width=0.3', 'height=0.3', 'sigma=0.02357', 's2=sigma**2/2', 'alpha_1=1500', 'beta_1=5.56e-4',
+            's_1_1=0.01', 'gamma_1_1=0.01', 'D_1_1=1e-6', 'variance_rate=1e-4', 'variance_interval=0.01', 'dt=0.004', 'atol=0.01',
+            'rtol=1e-6', '--petsc', '-ts_adapt_type', 'none', '--']
+    whole = solver.main('ksfd', *base, 'maxsteps=9')
+    whole.cleanup()
+    uninterrupted, log[:] = list(log), []
+    for how in ('--check', '--save'):                                           # checkpoint files (as in the reference) and series
+        log[:] = []
+        p = str(tmp_path / how[2:] / 'run')
+        first = solver.main('ksfd', *base, 'maxsteps=4', how + '=' + p)        # stops between two injections (t = 0.016)
+        first.cleanup()
+        src = p + '_4_' if how == '--check' else p                             # checkpointMonitor: one series per step, <prefix>_<k>_
+        second = solver.main('ksfd', *[b for b in base if not b.startswith('dt=')], 'maxsteps=5', '--resume=' + src)
+        second.cleanup()
+        assert len(uninterrupted) >= 3
+        assert log == uninterrupted, how

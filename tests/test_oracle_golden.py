@@ -99,7 +99,7 @@ def test_oracle_groom_active(name):
 STEP_TOL = 1e-11
 
 
-@pytest.mark.parametrize('name', [n for n in golden_cases('step_') if 'manufactured' not in n])
+@pytest.mark.parametrize('name', [n for n in golden_cases('step_') if 'manufactured' not in n and 'tdep' not in n])
 def test_oracle_step_vs_reference_lu_golden(name):
     """oracle RA34PW2 (dense LU and GMRES) vs golden = reference operators + sparse LU + same tableau"""
     z = load_golden(name)
@@ -117,6 +117,45 @@ def test_oracle_step_vs_reference_lu_golden(name):
         un, err, wr, _ = o.rosw_step(un, h, atol, rtol, solver='lu')
         assert abs(wr - z['wrms'][s]) <= 1e-6 * z['wrms'][s]
     assert rel_l2(un, cijk_to_soa(z['uN'])) < STEP_TOL
+
+
+def test_oracle_operators_with_stage_time_parameters_vs_reference_golden():
+    """step_2d_n1_tdep.npz (s_1_1, beta_1 expressions of t): the oracle's RHS with the stage-time tables and its assembled
+    Jacobian with the step-start table, driven by the restated tableau + exact sparse LU, reproduce the reference-operator
+    steps -- i.e. the per-stage semantics of ps.values(t) (KSFD/ksfdsym.py:1303-1312, 1430-1439)"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    z = load_golden('step_2d_n1_tdep')
+
+    def cfg_at(k, i):
+        return ProblemConfig(dim=int(z['dim']), n=tuple(int(x) for x in z['n']), L=tuple(float(x) for x in z['L']),
+                             lig_group=z['lig_group'], lig_w=z['tdep_lig_w'][k, i], lig_s=z['tdep_lig_s'][k, i],
+                             lig_gamma=z['tdep_lig_gamma'][k, i], lig_D=z['tdep_lig_D'][k, i],
+                             grp_alpha=z['tdep_grp_alpha'][k, i], grp_beta=z['tdep_grp_beta'][k, i],
+                             s2=float(z['tdep_s2'][k, i]), rhomax=float(z['tdep_rhomax'][k, i]), cushion=float(z['tdep_cushion'][k, i]),
+                             maxscale=float(z['tdep_maxscale'][k, i]), rhomin=float(z['rhomin']), Umin=float(z['Umin']),
+                             cap_kind=int(z['cap_kind']))
+    At, Gi, bt, b2t, asum = ko.tableau()
+    gam = 1.0 / Gi[0, 0]
+    u = cijk_to_soa(z['u0'])
+    h = float(z['h'])
+    F, N = int(z['nlig']) + 1, u.size // (int(z['nlig']) + 1)
+    to_vec = lambda a: a.reshape(F, N).T.reshape(-1)             # SoA -> the CSR's unknown order F*p + dof
+    to_soa = lambda x: x.reshape(N, F).T.reshape(-1)
+    for k in range(int(z['nsteps'])):
+        rp, col, val = ko.Oracle(cfg_at(k, 0)).jacobian_csr(u)
+        J = sp.csr_matrix((val, col, rp), shape=(F * N, F * N))
+        lu = spla.splu((sp.identity(F * N, format='csc') / (gam * h) - J).tocsc())
+        Y = []
+        for i in range(4):
+            Z = u + sum(At[i, j] * Y[j] for j in range(i))
+            Zdot = sum((Gi[i, j] / h) * Y[j] for j in range(i)) if i else 0.0
+            rhs = ko.Oracle(cfg_at(k, i + 1)).rhs(Z) - Zdot
+            Y.append(to_soa(lu.solve(to_vec(rhs))))
+        u = u + sum(bt[j] * Y[j] for j in range(4))
+        if k == 0:
+            assert rel_l2(u, cijk_to_soa(z['u1'])) < STEP_TOL
+    assert rel_l2(u, cijk_to_soa(z['uN'])) < STEP_TOL
 
 
 def test_oracle_manufactured_known_answer():
