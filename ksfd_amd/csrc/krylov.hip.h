@@ -439,13 +439,16 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
     const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
     const int maxit = std::min(o->ksp_max_it > 0 ? o->ksp_max_it : 2000, 24);
     double *r = h->Z;                              // residual (the fused-stage path leaves Z unused)
+    float *r32 = reinterpret_cast<float *>(h->Z);  // ... kept in fp32 while only the preconditioner reads it
     double rn = bn, rprev = bn;
-    const bool fused = fused_ok(h);
+    const bool fused = fused_ok(h) && h->size == 1;
     bool slow = false;
     for (int k = 0; k < maxit; k++) {
-        if ((rc = spec_apply(h, shift, k == 0 ? b : r, x, k == 0 ? nullptr : x))) return rc;
+        if (k == 0) rc = spec_apply(h, shift, b, x);
+        else rc = fused ? spec_apply(h, shift, nullptr, x, x, r32) : spec_apply(h, shift, r, x, x);
+        if (rc) return rc;
         if (fused) {
-            if ((rc = op_jvp_frozen(h, x, 2, shift, r, b, 0.0, 0.0, true))) return rc;      // r = b - A x, ||r||^2 -> hres[0]
+            if ((rc = op_residual32(h, x, shift, b, r32))) return rc;                          // r = b - A x (fp32 copy), ||r||^2 -> hres[0]
         } else {
             if ((rc = op_jvp_frozen(h, x, 2, shift, r, b)) || (rc = op_multidot(h, r, r, 0))) return rc;
         }
@@ -456,6 +459,7 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
         if (rn > 0.25 * rprev) { slow = true; break; }
         rprev = rn;
     }
+    if (fused && (rc = op_jvp_frozen(h, x, 2, shift, r, b))) return rc;       // the correction solve below wants the residual in fp64
     if (!slow && rn > tol) slow = true;
     // hand the correction equation A d = r to flexible GMRES with the same preconditioner (absolute tolerance = ours)
     ksfd_step_opts go = *o;

@@ -293,15 +293,27 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
 // as half as many doubles (inner and plane are even on this path).
 template <typename TC, typename TV, typename TY, typename TO>
 static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const TC *C, const TV *v, int mode, double shift,
-                          TO *out, const TY *yadd, double alpha, double beta)
+                          TO *out, const TY *yadd, double alpha, double beta, double *normpart = nullptr)
 {
     const KGeom &G = h->G;
     const double per_pt = (3.0 + h->P.nlig) * sizeof(TC) + G.F * (double)(sizeof(TV) + sizeof(TO)) + ((mode == 2 || mode == 3) ? G.F * (double)sizeof(TY) : 0.0);
     Scope sc(h, KC_JVP, per_pt * (double)G.nloc * frac, 8.0 * (3.0 * G.F + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc * frac);
     NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, TC, TV, TY, TO>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st,
-                                                                     G, h->P, K, C, (const TV *)v, mode, shift, out, yadd, alpha, beta));
+                                                                     G, h->P, K, C, (const TV *)v, mode, shift, out, yadd, alpha, beta, KSmooth{}, normpart));
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
+}
+
+// r32 = b - A x stored in fp32 (its only reader is the spectral preconditioner, which works in fp32 anyway) with ||r||^2 in
+// fp64 from the store epilogue -> h->hres[0].  Single rank, strip kernels.
+static int op_residual32(ksfd_handle *h, const double *x, double shift, const double *b, float *r32)
+{
+    KStrips K = make_strips(h, true);
+    const long long nwaves = (long long)K.nstrips * K.nseg;
+    if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");
+    int rc = jvp2d_launch_t<double, double, double, float>(h, K, 1.0, (const double *)h->coef, x, 2, shift, r32, b, 0.0, 0.0, h->part);
+    if (rc) return rc;
+    return reduce_rows(h, 1, (int)nwaves, 0);
 }
 
 template <typename TC, typename TV, typename TY, typename TO>

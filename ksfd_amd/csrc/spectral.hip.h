@@ -148,6 +148,56 @@ __device__ __forceinline__ void kspec_stage(kcf *lds, int sstride, int nseq, int
     }
 }
 
+// Stage 0 (radix 16, L = n: every plan starts with it) fused with the global-memory side of a kernel:
+//   forward: the 16 butterfly inputs come straight from ld(sequence, element) -- no staging pass through the LDS, and the
+//            16 loads of a thread are all in flight at once; outputs go to the LDS for the remaining stages
+//   inverse: the last stage of the DIT inverse hands its 16 outputs to st(sequence, element, value)
+// Consecutive lanes own consecutive elements, so every load/store instruction of a wave is one contiguous run.
+template <typename LD>
+__device__ __forceinline__ void kspec_stage0_fwd_from(kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw, LD ld)
+{
+    const int lg_S = lg_n - 4, S = 1 << lg_S;
+    const int total = nseq << lg_S;
+    for (int item = threadIdx.x; item < total; item += blockDim.x) {
+        const int s = item >> lg_S, i = item & (S - 1);
+        kcf x[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = ld(s, i + (q << lg_S));
+        kc_dft<16, false>(x);
+        if (lg_S > 0) {
+            const kcf w1 = tw[i];
+            kcf w = w1;
+#pragma unroll
+            for (int q = 1; q < 16; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+        }
+        kcf *base = lds + (long long)s * sstride;
+#pragma unroll
+        for (int q = 0; q < 16; q++) base[kspec_pad(i + (q << lg_S))] = x[q];
+    }
+}
+template <typename ST>
+__device__ __forceinline__ void kspec_stage0_inv_to(const kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw, ST st)
+{
+    const int lg_S = lg_n - 4, S = 1 << lg_S;
+    const int total = nseq << lg_S;
+    for (int item = threadIdx.x; item < total; item += blockDim.x) {
+        const int s = item >> lg_S, i = item & (S - 1);
+        const kcf *base = lds + (long long)s * sstride;
+        kcf x[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = base[kspec_pad(i + (q << lg_S))];
+        if (lg_S > 0) {
+            const kcf w1 = kc_conj(tw[i]);
+            kcf w = w1;
+#pragma unroll
+            for (int q = 1; q < 16; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+        }
+        kc_dft<16, true>(x);
+#pragma unroll
+        for (int q = 0; q < 16; q++) st(s, i + (q << lg_S), x[q]);
+    }
+}
+
 template <bool INV>
 __device__ __forceinline__ void kspec_stage_any(int radix, kcf *lds, int sstride, int nseq, int lg_n, int lg_L, const kcf *__restrict__ tw)
 {
@@ -160,20 +210,22 @@ __device__ __forceinline__ void kspec_stage_any(int radix, kcf *lds, int sstride
 }
 __device__ __forceinline__ int kspec_lg(int r) { return r == 16 ? 4 : (r == 8 ? 3 : (r == 4 ? 2 : 1)); }
 
-// all stages; the caller has synchronised after filling the LDS; returns synchronised
-__device__ __forceinline__ void kspec_fft_fwd(const KFFTPlan &P, kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw)
+// all stages from `first` on; the caller has synchronised after filling the LDS; returns synchronised
+__device__ __forceinline__ void kspec_fft_fwd(const KFFTPlan &P, kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw, int first = 0)
 {
     int lg_L = P.lg;
-    for (int s = 0; s < P.nstage; s++) {
+    for (int s = 0; s < first; s++) lg_L -= kspec_lg(P.radix[s]);
+    for (int s = first; s < P.nstage; s++) {
         kspec_stage_any<false>(P.radix[s], lds, sstride, nseq, P.lg, lg_L, tw);
         __syncthreads();
         lg_L -= kspec_lg(P.radix[s]);
     }
 }
-__device__ __forceinline__ void kspec_fft_inv(const KFFTPlan &P, kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw)
+// stages nstage-1 ... last (0 = all of them)
+__device__ __forceinline__ void kspec_fft_inv(const KFFTPlan &P, kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw, int last = 0)
 {
     int lg_L = 0;
-    for (int s = P.nstage - 1; s >= 0; s--) {
+    for (int s = P.nstage - 1; s >= last; s--) {
         lg_L += kspec_lg(P.radix[s]);
         kspec_stage_any<true>(P.radix[s], lds, sstride, nseq, P.lg, lg_L, tw);
         __syncthreads();
@@ -188,19 +240,23 @@ __device__ __forceinline__ int kspec_tile(int b, int ntiles)
 }
 
 // rows of v (F fp64 planes, x fastest, no ghosts) -> W[pair][pos][y] ; blockIdx.y = pair
-__global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* column stride of W */, int rb, int ntiles, int F, const double *__restrict__ v, long long plane,
+// TIN: storage type of v (double; float for the defect-correction residual, which only this kernel ever reads)
+template <typename TIN>
+__global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* column stride of W */, int rb, int ntiles, int F, const TIN *__restrict__ v, long long plane,
                                                         kcf *__restrict__ W, const kcf *__restrict__ tw)
 {
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
     const int y0 = kspec_tile(blockIdx.x, ntiles < 0 ? -ntiles : ntiles) * rb;
     const int sstride = nx + (nx >> 4) + 1;
-    const double *va = v + (long long)(2 * p) * plane + (long long)y0 * nx;
+    const TIN *va = v + (long long)(2 * p) * plane + (long long)y0 * nx;
     const bool has_b = 2 * p + 1 < F;
-    const double *vb = has_b ? va + plane : va;
+    const TIN *vb = has_b ? va + plane : va;
     const int half = nx >> 1, lg_half = PX.lg - 1;
     const int lg_rb = 31 - __clz(rb);             // rb is a power of two (spec_build)
-    // loads in batches of 4 items per thread, all issued before the first LDS store (one memory latency per batch, not per item)
+    // loads in batches of 4 items per thread, all issued before the first LDS store (one memory latency per batch, not per item).
+    // (Measured and dropped: feeding the first radix-16 stage straight from global memory -- 128 VGPRs + spills at 1024 threads,
+    //  151 -> 187 us; the same fusion on the store side of the inverse kernel is kept, it has the registers to spare.)
     for (int base = 0; base < rb * half; base += 4 * blockDim.x) {
         double2 a[4], b[4];
 #pragma unroll
@@ -209,8 +265,8 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
             a[u] = b[u] = make_double2(0.0, 0.0);
             if (idx < rb * half) {
                 const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
-                a[u] = *reinterpret_cast<const double2 *>(va + (long long)r * nx + x);
-                if (has_b) b[u] = *reinterpret_cast<const double2 *>(vb + (long long)r * nx + x);
+                a[u] = ksfd_ld2(va + (long long)r * nx + x);
+                if (has_b) b[u] = ksfd_ld2(vb + (long long)r * nx + x);
             }
         }
 #pragma unroll
@@ -266,22 +322,27 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
         }
     }
     __syncthreads();
-    kspec_fft_inv(PX, kspec_lds, sstride, rb, tw);
     const bool has_b = 2 * p + 1 < F;
-    const int half = nx >> 1;
+    const long long o0 = (long long)(2 * p) * plane + (long long)y0 * nx;
+    if (PX.nstage > 0) {
+        kspec_fft_inv(PX, kspec_lds, sstride, rb, tw, 1);
+        kspec_stage0_inv_to(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int e, kcf c) {
+            const long long o = o0 + (long long)r * nx + e;
+            double a = (double)c.x, b = (double)c.y;
+            if (xadd) { a += xadd[o]; if (has_b) b += xadd[o + plane]; }
+            z[o] = a;
+            if (has_b) z[o + plane] = b;
+        });
+        return;
+    }
+    const int half = nx >> 1;      // timing experiment only (KSFD_SPEC_DIAG): no transform
     for (int idx = threadIdx.x; idx < rb * half; idx += blockDim.x) {
         const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
         const kcf *row = kspec_lds + r * sstride;
         const kcf c0 = row[kspec_pad(x)], c1 = row[kspec_pad(x + 1)];
-        const long long o = (long long)(2 * p) * plane + (long long)(y0 + r) * nx + x;
-        double2 a = make_double2((double)c0.x, (double)c1.x), b = make_double2((double)c0.y, (double)c1.y);
-        if (xadd) {
-            const double2 xa = *reinterpret_cast<const double2 *>(xadd + o);
-            a.x += xa.x; a.y += xa.y;
-            if (has_b) { const double2 xb = *reinterpret_cast<const double2 *>(xadd + o + plane); b.x += xb.x; b.y += xb.y; }
-        }
-        *reinterpret_cast<double2 *>(z + o) = a;
-        if (has_b) *reinterpret_cast<double2 *>(z + o + plane) = b;
+        const long long o = o0 + (long long)r * nx + x;
+        *reinterpret_cast<double2 *>(z + o) = make_double2((double)c0.x, (double)c1.x);
+        if (has_b) *reinterpret_cast<double2 *>(z + o + plane) = make_double2((double)c0.y, (double)c1.y);
     }
 }
 
@@ -302,6 +363,8 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp,
     const int sstride = ny + (ny >> 4) + 1;
     const int nseq = 2 * npair;
     const int half = ny >> 1, lg_half = PY.lg - 1;
+    auto colbase = [&](int s) { return W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * nyp; };
+    // (first/last stage fused with the global loads/stores was measured here too: 154 VGPRs -> one block per CU, 134 -> 157 us)
     for (int base = 0; base < nseq * half; base += 8 * blockDim.x) {
         float4 t[8];
 #pragma unroll
@@ -309,7 +372,7 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp,
             const int idx = base + u * blockDim.x + threadIdx.x;
             if (idx < nseq * half) {
                 const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
-                t[u] = *reinterpret_cast<const float4 *>(W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * nyp + y);
+                t[u] = *reinterpret_cast<const float4 *>(colbase(s) + y);
             }
         }
 #pragma unroll
@@ -378,10 +441,9 @@ __global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp,
     kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
         const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
-        kcf *col = W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * nyp;
         const kcf *q = kspec_lds + s * sstride;
         const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
-        *reinterpret_cast<float4 *>(col + y) = make_float4(c0.x, c0.y, c1.x, c1.y);
+        *reinterpret_cast<float4 *>(colbase(s) + y) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
 

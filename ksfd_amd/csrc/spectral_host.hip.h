@@ -62,7 +62,8 @@ static void spec_build(ksfd_handle *h)
     S.lds_rows = row_bytes * rb;
     S.lds_cols = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * 2 * S.npair;
     if (S.lds_cols > lds_max - 1024) return;
-    if (hipFuncSetAttribute((const void *)k_spec_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
+    if (hipFuncSetAttribute((const void *)k_spec_rows_fwd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_spec_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         0) { hipGetLastError(); return; }
     {
@@ -114,7 +115,8 @@ static int spec_means(ksfd_handle *h)
 
 // z = M^-1 v, M = shift*I - J0 (constant-coefficient part of the frozen Jacobian)
 // xadd != NULL: z = xadd + M^-1 v (one Richardson update without a vector pass of its own)
-static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, const double *xadd = nullptr)
+// v32 != NULL: the input is that fp32 copy (F planes of floats, same geometry) instead of v
+static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, const double *xadd = nullptr, const float *v32 = nullptr)
 {
     SpecState &S = h->spec;
     const KGeom &G = h->G;
@@ -139,8 +141,9 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     if (getenv("KSFD_SPEC_THRC")) thr_cols = atoi(getenv("KSFD_SPEC_THRC"));
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
-        Scope sc(h, KC_SPECTRAL, 8.0 * fn + pn, 8.0 * fn);                      // read v | write W
-        hipLaunchKernelGGL(k_spec_rows_fwd, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v, G.plane, S.W, (const kcf *)S.twx);
+        Scope sc(h, KC_SPECTRAL, (v32 ? 4.0 : 8.0) * fn + pn, 8.0 * fn);        // read v | write W
+        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v32, G.plane, S.W, (const kcf *)S.twx);
+        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v, G.plane, S.W, (const kcf *)S.twx);
     }
     {
         Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // W in place
