@@ -267,7 +267,8 @@ def main():
         table = warm if args.warmup > 0 else prof             # all-class timings: warm-up steps (see above)
         tot_ms = sum(v['ms'] for v in table.values()) or 1.0
         kern = {k: dict(ms=round(v['ms'], 3), launches=int(v['launches']), share=round(v['ms'] / tot_ms, 3),
-                        GBs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
+                        GBs=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
+                        GBs_algorithmic=round(v['alg_bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
                 for k, v in table.items() if v['launches']}
         default_workload = world == 1 and args.n == 4096 and args.dim == 2 and args.nlig == 1
         traffic, traffic_src = pmc_traffic(dom) if default_workload else (None, None)

@@ -125,7 +125,8 @@ struct ksfd_handle {
     double mg_threshold = 75.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
     float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
-    bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path)
+    bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path; 3-D: inside the G pass + strip kernel)
+    bool rhs3d_strip = true;        // 3-D RHS: G pass + z-marching strip kernel (false: generic one-thread-per-point stencil pass)
     bool poly_fp32 = true;          // Horner temporaries and coefficients of p(A) in fp32 storage (the outer A z_j stays fp64)
 
     // asynchronous snapshots for writers (ksfd_snapshot_begin / _wait): layout transform on the compute stream into a
@@ -293,4 +294,9 @@ static int alloc_d(ksfd_handle *h, double **p, int64_t n)
 static bool fused_ok(const ksfd_handle *h)
 {
     return h->use_fused && h->G.dim == 2 && (h->G.nx % 2 == 0) && h->G.nx >= 4 && h->G.sloc >= 4 && h->P.nlig <= 4;
+}
+// 3-D z-marching strip kernels (k_jvp3d_frozen, k_rhs3d_strip)
+static bool strip3d_ok(const ksfd_handle *h)
+{
+    return h->use_fused && h->G.dim == 3 && (h->G.nx % 2 == 0) && h->G.nx >= 4 && h->P.nlig <= 4;
 }

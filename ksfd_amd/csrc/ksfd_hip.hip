@@ -639,7 +639,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && !(opts->reserved & 1) && stiff >= 1e-3 &&
                                (h->size == 1 || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
-        const bool fuse_stage = fused_ok(h) && h->P.nlig <= 4 && h->fuse_stage;
+        const bool fuse_stage = (fused_ok(h) || (strip3d_ok(h) && h->rhs3d_strip)) && h->P.nlig <= 4 && h->fuse_stage;
         const int its_before = st.linear_its;
         bool spec_failed = false;
         for (int i = 0; i < 4 && !rc; i++) {
@@ -893,6 +893,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->poly_fp32 = !(use_fused & 512);
         h->fuse_stage = !(use_fused & 1024);
         h->zero_copy = !(use_fused & 2048) && h->hres_dev;
+        h->rhs3d_strip = !(use_fused & 8192);
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

@@ -93,6 +93,25 @@ static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
     return S;
 }
 
+// launch geometry of the 3-D z-marching strip kernels
+static K3D make_k3d(const ksfd_handle *h)
+{
+    const KGeom &G = h->G;
+    K3D K;
+    K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+    K.nygrp = (int)((G.ny + 3) / 4);
+    K.zseg = h->zseg;
+    {
+        long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // blocks of 4 waves
+        if (fit < 2) fit = 2;
+        if (fit < K.zseg) K.zseg = (int)fit;
+    }
+    K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
+    const long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
+    K.nblocks = (int)((nb3 + 7) / 8 * 8);
+    return K;
+}
+
 static KSrc src_of(const ksfd_handle *h, int stage)
 {
     KSrc s;
@@ -124,6 +143,20 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         if (fused_norm) return reduce_rows(h, 1, (int)nwaves, 0);
         if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm needs the strip kernels");
         return KSFD_OK;
+    } else if (strip3d_ok(h) && h->rhs3d_strip) {
+        // 3-D: G plane (+ the stage argument, when the stage algebra rides along), then the z-marching 13-point star
+        if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm is a 2-D feature");
+        KComb C = cmb ? *cmb : KComb{};
+        const double *uin = u;
+        const int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * ((1 + C.nin) * G.F + (C.nin ? G.F : 0) + 1) * (double)G.plane, C.nin ? vbytes(h, 2 + C.nin) : 0.0);
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_gfield_comb<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, PP, u, C, C.nin ? h->Z : (double *)nullptr, h->Gb));
+        }
+        if (C.nin) uin = h->Z;
+        K3D K = make_k3d(h);
+        Scope sc(h, KC_RHS, 8.0 * (2.0 * G.F + 1 + C.nout * G.F) * (double)G.nloc, vbytes(h, 2 + C.nout));
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs3d_strip<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, uin, (const double *)h->Gb, S, out, C));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -213,18 +246,7 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
             Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, v, h->dGb));
         }
-        K3D K;
-        K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-        K.nygrp = (int)((G.ny + 3) / 4);
-        K.zseg = h->zseg;
-        {
-            long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // blocks of 4 waves
-            if (fit < 2) fit = 2;
-            if (fit < K.zseg) K.zseg = (int)fit;
-        }
-        K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
-        long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
-        K.nblocks = (int)((nb3 + 7) / 8 * 8);
+        K3D K = make_k3d(h);
         Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc, alg);
         NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     } else {

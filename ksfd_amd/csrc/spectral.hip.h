@@ -30,7 +30,7 @@
 #pragma once
 
 typedef float2 kcf;
-#define KSPEC_MAXSTAGE 4
+#define KSPEC_MAXSTAGE 7
 struct KFFTPlan {
     int n, lg, nstage;
     int radix[KSPEC_MAXSTAGE];     // DIF stage order; prod = n
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
     __syncthreads();
     const bool has_b = 2 * p + 1 < F;
     const long long o0 = (long long)(2 * p) * plane + (long long)y0 * nx;
-    if (PX.nstage > 0) {
+    if (PX.nstage > 0 && PX.radix[0] == 16) {
         kspec_fft_inv(PX, kspec_lds, sstride, rb, tw, 1);
         kspec_stage0_inv_to(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int e, kcf c) {
             const long long o = o0 + (long long)r * nx + e;
@@ -335,14 +335,21 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
         });
         return;
     }
-    const int half = nx >> 1;      // timing experiment only (KSFD_SPEC_DIAG): no transform
+    kspec_fft_inv(PX, kspec_lds, sstride, rb, tw);       // plans that do not start with radix 16 (experiment knob) / no transform (KSFD_SPEC_DIAG)
+    const int half = nx >> 1;
     for (int idx = threadIdx.x; idx < rb * half; idx += blockDim.x) {
         const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
         const kcf *row = kspec_lds + r * sstride;
         const kcf c0 = row[kspec_pad(x)], c1 = row[kspec_pad(x + 1)];
         const long long o = o0 + (long long)r * nx + x;
-        *reinterpret_cast<double2 *>(z + o) = make_double2((double)c0.x, (double)c1.x);
-        if (has_b) *reinterpret_cast<double2 *>(z + o + plane) = make_double2((double)c0.y, (double)c1.y);
+        double2 a = make_double2((double)c0.x, (double)c1.x), b = make_double2((double)c0.y, (double)c1.y);
+        if (xadd) {
+            const double2 xa = *reinterpret_cast<const double2 *>(xadd + o);
+            a.x += xa.x; a.y += xa.y;
+            if (has_b) { const double2 xb = *reinterpret_cast<const double2 *>(xadd + o + plane); b.x += xb.x; b.y += xb.y; }
+        }
+        *reinterpret_cast<double2 *>(z + o) = a;
+        if (has_b) *reinterpret_cast<double2 *>(z + o + plane) = b;
     }
 }
 
@@ -350,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
 // (templated on the ligand count: the per-point arrays of the symbol stage must stay in registers -- with run-time loop
 //  bounds they went to scratch memory and the kernel took 126 us of pure data movement)
 template <int NL>
-__global__ void __launch_bounds__(512) k_spec_cols(KFFTPlan PY, int nx, int nyp, kcf *__restrict__ W, const kcf *__restrict__ tw,
+__global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nx, int nyp, kcf *__restrict__ W, const kcf *__restrict__ tw,
                                                    const int *__restrict__ posx, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {

@@ -9,9 +9,10 @@ static bool spec_plan(long long n, KFFTPlan &P)
     while ((1LL << lg) < n) lg++;
     P.n = (int)n; P.lg = lg; P.nstage = 0;
     int left = lg;
-    while (left >= 4) { P.radix[P.nstage++] = 16; left -= 4; }
-    if (left) P.radix[P.nstage++] = 1 << left;
-    return P.nstage <= KSPEC_MAXSTAGE;
+    static const int lgmax = getenv("KSFD_SPEC_RADIX") ? (atoi(getenv("KSFD_SPEC_RADIX")) == 4 ? 2 : (atoi(getenv("KSFD_SPEC_RADIX")) == 8 ? 3 : 4)) : 4;   // experiment knob
+    while (left >= lgmax && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << lgmax; left -= lgmax; }
+    if (left && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << left; left = 0; }
+    return left == 0;
 }
 
 // position of frequency k in the output of the DIF stages (see spectral.hip.h): pos = q0*(n/r0) + pos'(k / r0), q0 = k % r0

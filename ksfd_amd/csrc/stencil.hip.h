@@ -1143,3 +1143,159 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
         }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// 3-D RHS, z-marching.  Two passes by design: G needs two logs and a tanh per point (fp64), and a single-pass kernel would
+// have to evaluate it for the y-halo rows of every block as well (1.5x at 8 rows per block) -- on this VALU-bound evaluation
+// that costs more than writing and re-reading one G plane.  Pass 1 (k_gfield_comb) forms the stage argument
+// z = u + sum_j a_j Y_j, stores it and G(z) over the slab incl. ghost units; pass 2 (this kernel) is the 13-point star with
+// the same strip / register-window / wave-shuffle scheme as k_jvp3d_frozen (z-neighbours in 5-plane windows, x-neighbours by
+// DPP shifts, the 4 y-neighbour rows of the centre plane by 16-B loads that hit L1/L2), and adds -sum_j c_j Y_j / h and the
+// sources at the store, so a 3-D step has no separate stage-vector passes either.
+// ---------------------------------------------------------------------------------------------
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_gfield_comb(KGeom G, KPhys P, const double *__restrict__ u, KComb cmb,
+                                                            double *__restrict__ zout, double *__restrict__ Gout)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < G.plane; e += stride) {
+        double val[NL + 1];
+#pragma unroll
+        for (int c = 0; c <= NL; c++) val[c] = u[(long long)c * G.plane + e];
+        for (int j = 0; j < cmb.nin; j++) {
+            const double a = cmb.ain[j];
+#pragma unroll
+            for (int c = 0; c <= NL; c++) val[c] += a * cmb.yin[j][(long long)c * G.plane + e];
+        }
+        if (zout) {
+#pragma unroll
+            for (int c = 0; c <= NL; c++) zout[(long long)c * G.plane + e] = val[c];
+        }
+        double U[NL], GU[NL], g, gr;
+        const double rho = ksfd_clamp(val[0], P.rhomin);
+#pragma unroll
+        for (int l = 0; l < NL; l++) U[l] = ksfd_clamp(val[l + 1], P.Umin);
+        ksfd_G<NL, false>(P, rho, U, g, gr, GU);
+        Gout[e] = g;
+    }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(KSFD_BLOCK) k_rhs3d_strip(KGeom G, KPhys P, K3D S, const double *__restrict__ u,
+                                                            const double *__restrict__ Gb, KSrc src, double *__restrict__ out,
+                                                            KComb cmb)
+{
+    const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x >> 6;
+    const long long bid = ksfd_xcd_remap(blockIdx.x, S.nblocks);
+    const long long nb_valid = (long long)S.nstrips * S.nygrp * S.nzseg;
+    if (bid >= nb_valid) return;
+    const int strip = (int)(bid % S.nstrips);
+    const long long ygrp = (bid / S.nstrips) % S.nygrp, zs = bid / ((long long)S.nstrips * S.nygrp);
+    const long long y = ygrp * (KSFD_BLOCK / KSFD_WAVE) + wv;
+    if (y >= G.ny) return;                                   // whole wave; no block barrier in this kernel
+    const long long half = G.nx >> 1;
+    const long long xs = 2 * ((long long)strip * half / S.nstrips), xe = 2 * ((long long)(strip + 1) * half / S.nstrips);
+    long long c0 = (xs - 2 + 2 * lane) % G.nx;
+    if (c0 < 0) c0 += G.nx;
+    const bool store = lane >= 1 && lane <= (int)((xe - xs) >> 1);
+    const long long k0 = zs * S.zseg, k1 = k0 + S.zseg < G.sloc ? k0 + S.zseg : G.sloc;
+    const bool up = (zs & 1) == 0;
+    auto kmap = [&](long long q) { return up ? q : (k0 + k1 - 1 - q); };
+    const long long rowc = y * G.nx + c0;
+    long long yo[4];
+    {
+        const int dm[4] = { -2, -1, 1, 2 };
+#pragma unroll
+        for (int q = 0; q < 4; q++) { long long yy = (y + dm[q]) % G.ny; if (yy < 0) yy += G.ny; yo[q] = yy * G.nx + c0; }
+    }
+    double rw[5][2], gw[5][2], uw[NL][5][2];
+    double nr[2], ng[2], nu[NL][2];
+    auto load_plane = [&](long long k) {
+        const long long o = ksfd_planeoff(G, k) + rowc;
+        const double2 a = ksfd_ld2(u + o), b = ksfd_ld2(Gb + o);
+        nr[0] = a.x; nr[1] = a.y; ng[0] = b.x; ng[1] = b.y;
+#pragma unroll
+        for (int l = 0; l < NL; l++) { const double2 z = ksfd_ld2(u + (long long)(l + 1) * G.plane + o); nu[l][0] = z.x; nu[l][1] = z.y; }
+    };
+    auto push = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                rw[s][e] = rw[s + 1][e]; gw[s][e] = gw[s + 1][e];
+#pragma unroll
+                for (int l = 0; l < NL; l++) uw[l][s][e] = uw[l][s + 1][e];
+            }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            rw[4][e] = ksfd_clamp(nr[e], P.rhomin); gw[4][e] = ng[e];
+#pragma unroll
+            for (int l = 0; l < NL; l++) uw[l][4][e] = ksfd_clamp(nu[l][e], P.Umin);
+        }
+    };
+    for (int q = -2; q <= 1; q++) { load_plane(kmap(k0 + q)); push(); }
+    load_plane(kmap(k0 + 2));
+    for (long long k = k0; k < k1; k++) {
+        push();
+        if (k + 1 < k1) load_plane(kmap(k + 3));
+        const long long kc = kmap(k);
+        const long long po = ksfd_planeoff(G, kc);
+        double2 yr[4], yg[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { yr[q] = ksfd_ld2(u + po + yo[q]); yg[q] = ksfd_ld2(Gb + po + yo[q]); }
+        const KX xr = ksfd_xnb(rw[2][0], rw[2][1]), xg = ksfd_xnb(gw[2][0], gw[2][1]);
+        double d1r[2], d1g[2], d2g[2];
+        ksfd_dx(rw[2][0], rw[2][1], xr, d1r[0], d1r[1]);
+        ksfd_dx(gw[2][0], gw[2][1], xg, d1g[0], d1g[1]);
+        ksfd_dxx(gw[2][0], gw[2][1], xg, d2g[0], d2g[1]);
+        double res[NL + 1][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double ih0 = P.inv_h[0], ih1 = P.inv_h[1], ih2 = P.inv_h[2];
+#define KY(arr, q) (e ? arr[q].y : arr[q].x)
+#define KYC(arr, q) ksfd_clamp(KY(arr, q), P.rhomin)
+            const double yr1 = KSFD_D1(KYC(yr, 0), KYC(yr, 1), KYC(yr, 2), KYC(yr, 3)) * ih1;
+            const double yg1 = KSFD_D1(KY(yg, 0), KY(yg, 1), KY(yg, 2), KY(yg, 3)) * ih1;
+            const double yg2 = KSFD_D2(KY(yg, 0), KY(yg, 1), gw[2][e], KY(yg, 2), KY(yg, 3)) * P.inv_h2[1];
+            const double zr1 = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * ih2;
+            const double zg1 = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * ih2;
+            const double zg2 = KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[2];
+            res[0][e] = (d1r[e] * ih0) * (d1g[e] * ih0) + yr1 * yg1 + zr1 * zg1 + rw[2][e] * (d2g[e] * P.inv_h2[0] + yg2 + zg2);
+#undef KYC
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const double *ul = u + (long long)(l + 1) * G.plane + po;
+            double2 yz[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) yz[q] = ksfd_ld2(ul + yo[q]);
+            const KX xz = ksfd_xnb(uw[l][2][0], uw[l][2][1]);
+            double d2z[2];
+            ksfd_dxx(uw[l][2][0], uw[l][2][1], xz, d2z[0], d2z[1]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+#define KYU(q) ksfd_clamp(KY(yz, q), P.Umin)
+                const double lap = d2z[e] * P.inv_h2[0] + KSFD_D2(KYU(0), KYU(1), uw[l][2][e], KYU(2), KYU(3)) * P.inv_h2[1] +
+                                   KSFD_D2(uw[l][0][e], uw[l][1][e], uw[l][2][e], uw[l][3][e], uw[l][4][e]) * P.inv_h2[2];
+                res[l + 1][e] = -P.lig_gamma[l] * uw[l][2][e] + P.lig_s[l] * rw[2][e] + P.lig_D[l] * lap;
+#undef KYU
+            }
+        }
+#undef KY
+        if (store) {
+            const long long pi = kc * G.nx * G.ny + rowc;              // dense interior index
+            const long long o = (long long)G.ng * G.inner + pi;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) {
+                double a = res[c][0], b = res[c][1];
+                if (src.p[c]) { const double2 sv = ksfd_ld2(src.p[c] + pi); a += sv.x; b += sv.y; }
+                for (int j = 0; j < cmb.nout; j++) {
+                    const double2 yv = ksfd_ld2(cmb.yout[j] + (long long)c * G.plane + o);
+                    a += cmb.aout[j] * yv.x; b += cmb.aout[j] * yv.y;
+                }
+                ksfd_st2(out + (long long)c * G.plane + o, a, b);
+            }
+        }
+    }
+}

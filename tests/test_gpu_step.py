@@ -20,11 +20,12 @@ def fixed_opts(z, **kw):
                                   ksp_max_it=4000, **kw)
 
 
-@pytest.mark.parametrize('orth,tuning', [(0, 1), (1, 1), (0, 3), (0, 0), (0, 1 | 8), (0, 1 | 16)])
+@pytest.mark.parametrize('orth,tuning', [(0, 1), (1, 1), (0, 3), (0, 0), (0, 1 | 8), (0, 1 | 16), (0, 1 | 8192)])
 @pytest.mark.parametrize('name', [n for n in golden_cases('step_') if 'manufactured' not in n and 'tdep' not in n])
 def test_fixed_steps_vs_reference_lu_golden(name, orth, tuning):
     """orth 0: CGS2 with algebraic second projection, 1: classic CGS2; tuning bit0 fused kernels, bit1 recompute J,
-    bit3 pipelined (device-resident) GMRES forced, bit4 pipelined GMRES off"""
+    bit3 pipelined (device-resident) GMRES forced, bit4 no Krylov recycling, bit13 3-D RHS through the generic stencil pass
+    instead of the z-marching strip kernel (the default)"""
     z = load_golden(name)
     cfg = ProblemConfig.from_golden(z)
     k = klib.KSFDHip(cfg)

@@ -23,7 +23,7 @@ shutil.copy(ks, 'profiles/%s_kernel_stats.csv' % tag)
 CLASS = [('k_rhs', 'rhs'), ('k_jvp', 'jvp'), ('k_multidot', 'multidot'), ('k_gs_update', 'gs_update'),
          ('k_lincomb', 'lincomb'), ('k_basis_axpy', 'basis_axpy'), ('k_rosw_finish', 'rosw_finish'),
          ('k_reduce_rows', 'reduce'), ('k_gfield', 'gfield'), ('k_jcoef', 'gfield'), ('k_dg_frozen', 'gfield'),
-         ('k_velocity', 'velocity'), ('k_spec', 'spectral'), ('k_mg_', 'mg'), ('k_cheb', 'mg'), ('k_restrict', 'mg'), ('k_prolong', 'mg')]
+         ('k_velocity', 'velocity'), ('k_velmax', 'velocity'), ('k_spec', 'spectral'), ('k_mg_', 'mg'), ('k_cheb', 'mg'), ('k_restrict', 'mg'), ('k_prolong', 'mg')]
 
 
 def cls_of(name):
