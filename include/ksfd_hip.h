@@ -69,6 +69,9 @@ typedef struct ksfd_config {
 typedef int (*ksfd_exchange_fn)(void *ctx, const double *send_lo, const double *send_hi,
                                 double *recv_lo, double *recv_hi, int64_t count);
 typedef int (*ksfd_allreduce_fn)(void *ctx, double *buf, int32_t count, int32_t op /*0 sum, 1 max*/);
+/* uniform all-to-all on host buffers: block q of `send` (bytes_per_peer bytes) goes to rank q, block r of `recv` comes from
+ * rank r (the own block included).  Optional: without it the spectral solver stays single-rank under transport 2. */
+typedef int (*ksfd_alltoall_fn)(void *ctx, const void *send, void *recv, int64_t bytes_per_peer);
 typedef struct ksfd_dist {
     int32_t rank, size;
     int32_t transport;
@@ -77,6 +80,7 @@ typedef struct ksfd_dist {
     ksfd_exchange_fn exchange;     /* transport 2 */
     ksfd_allreduce_fn allreduce;   /* transport 2 */
     void *ctx;
+    ksfd_alltoall_fn alltoall;     /* transport 2, may be NULL */
 } ksfd_dist;
 
 /* Time-step controls = the PETSc options every shipped options file passes

@@ -34,8 +34,11 @@ struct SpecState {
     KFFTPlan px, py;
     int rb = 0, npair = 0, nyp = 0;
     size_t lds_rows = 0, lds_cols = 0;
-    kcf *W = nullptr, *twx = nullptr, *twy = nullptr;
-    int *posx = nullptr, *posy = nullptr, *kyofpos = nullptr;
+    kcf *W = nullptr, *W2 = nullptr, *twx = nullptr, *twy = nullptr;     // W: [pair][pos_x][y_local]; W2: after the all-to-all, [rank][pair][own pos][y_local]
+    int *posy = nullptr, *kyofpos = nullptr;
+    int4 *pairtab = nullptr;          // per block of the column kernel
+    int nxl = 0, nblk_cols = 0, lg_pl = 0;   // owned positions, column-kernel blocks, log2(rows per rank)
+    std::vector<A2APiece> a2a_fwd_s, a2a_fwd_r, a2a_bwd_s, a2a_bwd_r;
     float *lx = nullptr, *ly = nullptr;
     double a_rr = 0.0, a_rU[KSFD_MAXL] = { 0 };
     // adaptation: steps (counted by ksfd_step calls) before which the automatic choice leaves it alone after it converged badly

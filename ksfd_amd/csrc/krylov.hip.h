@@ -441,12 +441,13 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
     double *r = h->Z;                              // residual (the fused-stage path leaves Z unused)
     float *r32 = reinterpret_cast<float *>(h->Z);  // ... kept in fp32 while only the preconditioner reads it
     double rn = bn, rprev = bn;
-    const bool fused = fused_ok(h) && h->size == 1;
+    const bool fused = fused_ok(h);
     bool slow = false;
     for (int k = 0; k < maxit; k++) {
         if (k == 0) rc = spec_apply(h, shift, b, x);
         else rc = fused ? spec_apply(h, shift, nullptr, x, x, r32) : spec_apply(h, shift, r, x, x);
         if (rc) return rc;
+        if (h->size > 1 && (rc = halo(h, x))) return rc;                                     // the spectral application wrote owned rows only
         if (fused) {
             if ((rc = op_residual32(h, x, shift, b, r32))) return rc;                          // r = b - A x (fp32 copy), ||r||^2 -> hres[0]
         } else {

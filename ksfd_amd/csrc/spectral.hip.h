@@ -356,21 +356,27 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
 // one block per {kx, -kx}: forward FFT along y, symbol, inverse FFT along y, in place in W
 // (templated on the ligand count: the per-point arrays of the symbol stage must stay in registers -- with run-time loop
 //  bounds they went to scratch memory and the kernel took 126 us of pure data movement)
+// Column storage: column (pair p, local position jl) consists of `ny >> lg_pl` pieces of 2^lg_pl elements, `pstride` elements
+// apart (one piece per slab rank after the all-to-all; a single piece of ny elements on one rank); pairtab[block] =
+// (jlA, jlB, kxA, self): the two local positions the block owns, the wavenumber of the first, and whether both are self-paired.
 template <int NL>
-__global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nx, int nyp, kcf *__restrict__ W, const kcf *__restrict__ tw,
-                                                   const int *__restrict__ posx, const int *__restrict__ posy, const int *__restrict__ kyofpos,
+__global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ tw,
+                                                   const int4 *__restrict__ pairtab, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
     constexpr int F = NL + 1, npair = (F + 1) / 2;
-    const int ny = PY.n, b = blockIdx.x;
-    const bool self = b == 0;                                   // kx = 0 and kx = nx/2 are their own partners
-    const int kxA = self ? 0 : b, kxB = self ? (nx >> 1) : nx - b;
-    const int jA = posx[kxA], jB = posx[kxB];
+    const int ny = PY.n;
+    const int4 pt = pairtab[blockIdx.x];
+    const bool self = pt.w != 0;                                // kx = 0 and kx = nx/2 are their own partners
+    const int jA = pt.x, jB = pt.y, kxA = pt.z, kxB = self ? pt.w - 1 : pt.z;     // lx is even: lx[-kx] = lx[kx]
     const int sstride = ny + (ny >> 4) + 1;
     const int nseq = 2 * npair;
     const int half = ny >> 1, lg_half = PY.lg - 1;
-    auto colbase = [&](int s) { return W + ((long long)(s >> 1) * nx + ((s & 1) ? jB : jA)) * nyp; };
+    const int plmask = (1 << lg_pl) - 1;
+    auto colat = [&](int s, int y) {                           // y even: a float4 never straddles two pieces
+        return W + (long long)(y >> lg_pl) * pstride + (((long long)(s >> 1) * nxl + ((s & 1) ? jB : jA)) << lg_pl) + (y & plmask);
+    };
     // (first/last stage fused with the global loads/stores was measured here too: 154 VGPRs -> one block per CU, 134 -> 157 us)
     for (int base = 0; base < nseq * half; base += 8 * blockDim.x) {
         float4 t[8];
@@ -379,7 +385,7 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nx, int nyp
             const int idx = base + u * blockDim.x + threadIdx.x;
             if (idx < nseq * half) {
                 const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
-                t[u] = *reinterpret_cast<const float4 *>(colbase(s) + y);
+                t[u] = *reinterpret_cast<const float4 *>(colat(s, y));
             }
         }
 #pragma unroll
@@ -450,7 +456,7 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nx, int nyp
         const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
         const kcf *q = kspec_lds + s * sstride;
         const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
-        *reinterpret_cast<float4 *>(colbase(s) + y) = make_float4(c0.x, c0.y, c1.x, c1.y);
+        *reinterpret_cast<float4 *>(colat(s, y)) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
 

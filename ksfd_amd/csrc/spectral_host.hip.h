@@ -31,7 +31,7 @@ static int spec_pos(const KFFTPlan &P, int k)
 static void spec_free(ksfd_handle *h)
 {
     SpecState &S = h->spec;
-    void *bufs[] = { S.W, S.twx, S.twy, S.posx, S.posy, S.kyofpos, S.lx, S.ly };
+    void *bufs[] = { S.W, S.W2, S.twx, S.twy, S.posy, S.kyofpos, S.pairtab, S.lx, S.ly };
     for (void *b : bufs) if (b) hipFree(b);
     S = SpecState();
 }
@@ -42,31 +42,40 @@ template <typename T> static bool spec_upload(T **dev, const std::vector<T> &hos
            hipMemcpy(*dev, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice) == hipSuccess;
 }
 
-// Builds plans, tables and the work array if this handle can use the spectral preconditioner; leaves spec.ok = false otherwise.
+// Slab ranks (P = 2, 4, 8): the x-transforms are local (a rank owns whole rows); for the y-transforms every rank needs whole
+// columns, so the transposed work array is redistributed by an all-to-all: rank q gets the spectral positions whose TOP digit
+// (= lowest radix-16 digit of kx) is in its share of the list below.  kx and -kx have top digits d and (16 - d) % 16, so with
+// the digits handed out in these pairs both columns of every {kx, -kx} pair land on one rank.
+static const int spec_digit_order[16] = { 0, 8, 1, 15, 2, 14, 3, 13, 4, 12, 5, 11, 6, 10, 7, 9 };
+
+// Builds plans, tables and the work arrays if this handle can use the spectral solver; leaves spec.ok = false otherwise.
 static void spec_build(ksfd_handle *h)
 {
     SpecState &S = h->spec;
     const KGeom &G = h->G;
+    const int P = h->size;
     S.ok = false;
-    if (G.dim != 2 || h->size != 1 || G.ng != 0) return;
-    if (!spec_plan(G.nx, S.px) || !spec_plan(G.ny, S.py)) return;
+    if (G.dim != 2) return;
+    if (P > 1 && (!h->tr || !h->tr->has_alltoall() || (P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
+    const long long ny = h->cfg.n[1], nyl = G.sloc;                  // global / local rows
+    if (!spec_plan(G.nx, S.px) || !spec_plan(ny, S.py)) return;
+    if (S.px.radix[0] != 16 || (nyl & (nyl - 1)) || nyl < 4) return;
     S.npair = (G.F + 1) / 2;
     const size_t lds_max = 160 * 1024;
     const size_t row_bytes = sizeof(kcf) * (size_t)(G.nx + (G.nx >> 4) + 1);
     int rb = (int)std::min<size_t>((lds_max - 1024) / row_bytes, 16);
-    while (rb > 1 && (G.ny % rb)) rb--;                              // power-of-two ny: rb ends up a power of two
+    while (rb > 1 && (nyl % rb)) rb--;                               // power-of-two rows: rb ends up a power of two
     if (rb < 1) return;
     // rows per block: as many as the LDS holds (wider store segments of the transposed write), but keep >= 2 tiles per CU
-    while (rb > 2 && G.ny / rb < 512) rb >>= 1;
+    while (rb > 2 && nyl / rb < 512) rb >>= 1;
     if (getenv("KSFD_SPEC_RB")) rb = std::max(1, std::min(rb, atoi(getenv("KSFD_SPEC_RB"))));
     S.rb = rb;
     S.lds_rows = row_bytes * rb;
-    S.lds_cols = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * 2 * S.npair;
+    S.lds_cols = sizeof(kcf) * (size_t)(ny + (ny >> 4) + 1) * 2 * S.npair;
     if (S.lds_cols > lds_max - 1024) return;
     if (hipFuncSetAttribute((const void *)k_spec_rows_fwd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
-        0) { hipGetLastError(); return; }
+        hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess) { hipGetLastError(); return; }
     {
         hipError_t e = hipSuccess;
         NL_DISPATCH(h->P.nlig, e = hipFuncSetAttribute((const void *)k_spec_cols<NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols));
@@ -77,20 +86,55 @@ static void spec_build(ksfd_handle *h)
         for (int k = 0; k < n; k++) { const double a = -2.0 * M_PI * k / n; t[k] = make_float2((float)cos(a), (float)sin(a)); }
         return t;
     };
-    auto positions = [](const KFFTPlan &P) { std::vector<int> p(P.n); for (int k = 0; k < P.n; k++) p[k] = spec_pos(P, k); return p; };
+    auto positions = [](const KFFTPlan &Q) { std::vector<int> p(Q.n); for (int k = 0; k < Q.n; k++) p[k] = spec_pos(Q, k); return p; };
     auto inverse = [](const std::vector<int> &p) { std::vector<int> q(p.size()); for (size_t k = 0; k < p.size(); k++) q[p[k]] = (int)k; return q; };
     auto symbol = [](int n, double inv_h2) {
         std::vector<float> l(n);
         for (int k = 0; k < n; k++) { const double th = 2.0 * M_PI * k / n; l[k] = (float)((-30.0 + 32.0 * cos(th) - 2.0 * cos(2.0 * th)) / 12.0 * inv_h2); }
         return l;
     };
-    // columns of W are padded by 256 B: with a power-of-two column stride every block of the column kernel (and every store
-    // segment of the transposed write) would walk the HBM channels in lockstep
-    S.nyp = (int)G.ny + (getenv("KSFD_SPEC_PAD") ? 32 : 0);      // (measured: a 256-B pad makes all three kernels ~5 % slower; no channel lockstep to break)
-    if (hipMalloc((void **)&S.W, sizeof(kcf) * (size_t)S.npair * G.nx * S.nyp) != hipSuccess ||
+    // ownership of spectral positions: top digit -> (rank, index of the digit in that rank's list)
+    const int nx = (int)G.nx, nx16 = nx / 16, ndig = 16 / P;
+    int dig_rank[16], dig_idx[16];
+    for (int q = 0; q < P; q++) for (int di = 0; di < ndig; di++) { const int d = spec_digit_order[q * ndig + di]; dig_rank[d] = q; dig_idx[d] = di; }
+    S.nxl = nx / P;
+    S.lg_pl = 0;
+    while ((1LL << S.lg_pl) < nyl) S.lg_pl++;
+    const std::vector<int> posx = positions(S.px);
+    // among the owner's positions (one rank: the work array is used in place, positions are their own index)
+    auto local_index = [&](int j) { return P == 1 ? j : dig_idx[j / nx16] * nx16 + (j % nx16); };
+    std::vector<int4> pairs;
+    for (int kx = 0; kx <= nx / 2; kx++) {
+        const int kxm = (nx - kx) % nx, j = posx[kx], jm = posx[kxm];
+        if (dig_rank[j / nx16] != h->rank) continue;
+        if (kx == 0) pairs.push_back(make_int4(local_index(posx[0]), local_index(posx[nx / 2]), 0, nx / 2 + 1));     // the two self-paired columns share a block
+        else if (kx != nx / 2) pairs.push_back(make_int4(local_index(j), local_index(jm), kx, 0));
+    }
+    S.nblk_cols = (int)pairs.size();
+    if (S.nblk_cols != S.nxl / 2) return;                            // (cannot happen for P in {1, 2, 4, 8}: the digit pairs keep kx and -kx together)
+    const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nyl;
+    S.nyp = (int)nyl;
+    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || (P > 1 && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
         !spec_upload(&S.twx, twiddles(S.px.n)) || !spec_upload(&S.twy, twiddles(S.py.n)) ||
-        !spec_upload(&S.posx, positions(S.px)) || !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) ||
+        !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) || !spec_upload(&S.pairtab, pairs) ||
         !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1]))) { hipGetLastError(); spec_free(h); return; }
+    if (P > 1) {
+        // pieces of the two all-to-alls: one per (peer, pair, top digit of the receiver) = nx/16 columns x nyl rows, contiguous on both sides
+        const size_t pbytes = sizeof(kcf) * (size_t)nx16 * nyl;
+        for (int q = 0; q < P; q++)
+            for (int p = 0; p < S.npair; p++)
+                for (int di = 0; di < ndig; di++) {
+                    const int dq = spec_digit_order[q * ndig + di], dme = spec_digit_order[h->rank * ndig + di];
+                    kcf *mine_for_q = S.W + ((size_t)p * nx + (size_t)dq * nx16) * nyl;                               // my rows of q's columns
+                    kcf *from_q = S.W2 + (((size_t)q * S.npair + p) * S.nxl + (size_t)di * nx16) * nyl;               // q's rows of my columns
+                    kcf *back_mine = S.W + ((size_t)p * nx + (size_t)dq * nx16) * nyl;
+                    (void)dme;
+                    S.a2a_fwd_s.push_back({ q, mine_for_q, pbytes });
+                    S.a2a_fwd_r.push_back({ q, from_q, pbytes });
+                    S.a2a_bwd_s.push_back({ q, from_q, pbytes });
+                    S.a2a_bwd_r.push_back({ q, back_mine, pbytes });
+                }
+    }
     S.ok = true;
 }
 
@@ -126,10 +170,12 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     memset(&Y, 0, sizeof Y);
     Y.nlig = h->P.nlig;
     Y.shift = (float)shift; Y.a_rr = (float)S.a_rr;
-    Y.scale = (float)(1.0 / ((double)G.nx * (double)G.ny));
+    Y.scale = (float)(1.0 / ((double)G.nx * (double)h->cfg.n[1]));
     Y.den_floor = (float)(0.02 * shift);
     for (int l = 0; l < h->P.nlig; l++) { Y.a_rU[l] = (float)S.a_rU[l]; Y.s[l] = (float)h->P.lig_s[l]; Y.gam[l] = (float)h->P.lig_gamma[l]; Y.D[l] = (float)h->P.lig_D[l]; }
-    const int ntiles = (int)(G.ny / S.rb);
+    const int ntiles = (int)(G.sloc / S.rb);
+    const long long goff = (long long)G.ng * G.inner;                // the row kernels address owned rows only
+    const long long ny_glob = h->cfg.n[1];
     // timing-only diagnostics (wrong results): KSFD_SPEC_DIAG bit0/1/2 = skip the FFT stages of the rows-fwd / cols / rows-inv kernel, bit3 = rows-fwd stores tile-major (contiguous)
     static const int diag = getenv("KSFD_SPEC_DIAG") ? atoi(getenv("KSFD_SPEC_DIAG")) : 0;
     KFFTPlan px_f = S.px, py_c = S.py, px_i = S.px;
@@ -138,22 +184,33 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     if (diag & 4) px_i.nstage = 0;
     int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
     if (getenv("KSFD_SPEC_THRR")) thr_rows = atoi(getenv("KSFD_SPEC_THRR"));
-    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * S.npair * G.ny / 16));
+    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * S.npair * ny_glob / 16));
     if (getenv("KSFD_SPEC_THRC")) thr_cols = atoi(getenv("KSFD_SPEC_THRC"));
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
         Scope sc(h, KC_SPECTRAL, (v32 ? 4.0 : 8.0) * fn + pn, 8.0 * fn);        // read v | write W
-        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v32, G.plane, S.W, (const kcf *)S.twx);
-        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v, G.plane, S.W, (const kcf *)S.twx);
+        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v32 + goff, G.plane, S.W, (const kcf *)S.twx);
+        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v + goff, G.plane, S.W, (const kcf *)S.twx);
+    }
+    kcf *Wc = S.W;
+    if (h->size > 1) {                                                // rows of everybody's columns -> whole columns of mine
+        Scope sc(h, KC_HALO, pn);
+        if (h->tr->alltoall(S.a2a_fwd_s, S.a2a_fwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
+        Wc = S.W2;
     }
     {
-        Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // W in place
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec_cols<NL>), dim3((unsigned)(G.nx / 2)), dim3(thr_cols), S.lds_cols, h->st, py_c, (int)G.nx, S.nyp, S.W, (const kcf *)S.twy,
-                           (const int *)S.posx, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y));
+        Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // work array in place
+        const long long pstride = (long long)S.npair * S.nxl << S.lg_pl;
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec_cols<NL>), dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)S.twy,
+                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y));
+    }
+    if (h->size > 1) {
+        Scope sc(h, KC_HALO, pn);
+        if (h->tr->alltoall(S.a2a_bwd_s, S.a2a_bwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
     }
     {
         Scope sc(h, KC_SPECTRAL, pn + (xadd ? 16.0 : 8.0) * fn, (xadd ? 16.0 : 8.0) * fn);     // read W (+ x) | write z
-        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)S.W, z, G.plane, (const kcf *)S.twx, xadd);
+        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)S.W, z + goff, G.plane, (const kcf *)S.twx, xadd ? xadd + goff : (const double *)nullptr);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;

@@ -12,11 +12,19 @@
 #include <rccl/rccl.h>
 #include <string>
 #include <string.h>
+#include <vector>
 
 #include "../../include/ksfd_hip.h"
 
+// one contiguous piece of an all-to-all: the k-th piece sent to a peer lands in the k-th piece that peer receives from us
+struct A2APiece { int peer; void *ptr; size_t bytes; };
+
 struct Transport {
     virtual ~Transport() {}
+    // personalised all-to-all of device memory (transposes of the slab-distributed spectral solver); every rank passes the same
+    // number and sizes of pieces per peer; pieces addressed to the own rank are copied on the device
+    virtual bool has_alltoall() const { return false; }
+    virtual int alltoall(const std::vector<A2APiece> &sends, const std::vector<A2APiece> &recvs, hipStream_t st) { (void)sends; (void)recvs; (void)st; err = "all-to-all not available on this transport"; return 1; }
     // fill the 2*ng ghost units of every field plane of vec from the ring neighbours
     virtual int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) = 0;
     virtual int allreduce(double *dev, int n, int op, hipStream_t st) = 0;   // op 0 sum, 1 max; in place
@@ -95,26 +103,78 @@ struct RcclTransport : Transport {
     {
         return chk(api.AllReduce(dev, dev, (size_t)n, ncclDouble, op ? ncclMax : ncclSum, comm, st), "ncclAllReduce");
     }
+    bool has_alltoall() const override { return true; }
+    int alltoall(const std::vector<A2APiece> &sends, const std::vector<A2APiece> &recvs, hipStream_t st) override
+    {
+        // own pieces: device copies in order; everything else: one group of point-to-point transfers (xGMI links in parallel)
+        size_t ks = 0, kr = 0;
+        while (true) {
+            while (ks < sends.size() && sends[ks].peer != rank) ks++;
+            while (kr < recvs.size() && recvs[kr].peer != rank) kr++;
+            if (ks >= sends.size() || kr >= recvs.size()) break;
+            if (sends[ks].bytes != recvs[kr].bytes) { err = "all-to-all: own pieces do not pair up"; return 1; }
+            if (hipMemcpyAsync(recvs[kr].ptr, sends[ks].ptr, sends[ks].bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { err = "all-to-all: device copy failed"; return 1; }
+            ks++; kr++;
+        }
+        if (chk(api.GroupStart(), "ncclGroupStart")) return 1;
+        for (const A2APiece &p : sends) if (p.peer != rank && chk(api.Send(p.ptr, p.bytes, ncclChar, p.peer, comm, st), "ncclSend")) return 1;
+        for (const A2APiece &p : recvs) if (p.peer != rank && chk(api.Recv(p.ptr, p.bytes, ncclChar, p.peer, comm, st), "ncclRecv")) return 1;
+        return chk(api.GroupEnd(), "ncclGroupEnd");
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
 struct CallbackTransport : Transport {
     ksfd_exchange_fn ex = nullptr;
     ksfd_allreduce_fn ar = nullptr;
+    ksfd_alltoall_fn a2a = nullptr;
     void *ctx = nullptr;
+    int nranks = 1;
+    char *a2a_send = nullptr, *a2a_recv = nullptr;   // pinned, grown on demand
+    size_t a2a_cap = 0;
     double *stage = nullptr;      // pinned: [send_lo | send_hi | recv_lo | recv_hi], each F*ng*inner
     double *hred = nullptr;       // pinned, 64 doubles
     size_t chunk = 0;
     bool init(const ksfd_dist *d, int F, long long inner)
     {
-        ex = d->exchange; ar = d->allreduce; ctx = d->ctx;
+        ex = d->exchange; ar = d->allreduce; a2a = d->alltoall; ctx = d->ctx; nranks = d->size;
         if (!ex || !ar) { err = "transport 2 needs exchange and allreduce callbacks"; return false; }
         chunk = (size_t)(F + 2) * 2 * inner;                  // F fields (+2: the 3+n coefficient planes of a coarse level fit too)
         if (hipHostMalloc((void **)&stage, sizeof(double) * chunk * 4, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&hred, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return false; }
         return true;
     }
-    ~CallbackTransport() override { if (stage) hipHostFree(stage); if (hred) hipHostFree(hred); }
+    ~CallbackTransport() override { if (stage) hipHostFree(stage); if (hred) hipHostFree(hred); if (a2a_send) hipHostFree(a2a_send); if (a2a_recv) hipHostFree(a2a_recv); }
+    bool has_alltoall() const override { return a2a != nullptr; }
+    int alltoall(const std::vector<A2APiece> &sends, const std::vector<A2APiece> &recvs, hipStream_t st) override
+    {
+        // pack the pieces per peer into pinned host memory (peer-major, piece order kept), let the host language move the
+        // blocks, unpack.  Slow by construction (two PCIe crossings): rehearsal / generic-launcher path
+        size_t per_peer = 0;
+        for (const A2APiece &p : sends) if (p.peer == 0) per_peer += p.bytes;
+        const size_t total = per_peer * (size_t)nranks;
+        if (total > a2a_cap) {
+            if (a2a_send) hipHostFree(a2a_send);
+            if (a2a_recv) hipHostFree(a2a_recv);
+            a2a_send = a2a_recv = nullptr; a2a_cap = 0;
+            if (hipHostMalloc((void **)&a2a_send, total, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&a2a_recv, total, hipHostMallocDefault) != hipSuccess) { err = "all-to-all: hipHostMalloc failed"; return 1; }
+            a2a_cap = total;
+        }
+        std::vector<size_t> off((size_t)nranks, 0);
+        for (const A2APiece &p : sends) {
+            if (off[p.peer] + p.bytes > per_peer) { err = "all-to-all: uneven pieces"; return 1; }
+            if (hipMemcpyAsync(a2a_send + (size_t)p.peer * per_peer + off[p.peer], p.ptr, p.bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { err = "all-to-all D2H failed"; return 1; }
+            off[p.peer] += p.bytes;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) { err = "all-to-all: stream sync failed"; return 1; }
+        if (a2a(ctx, a2a_send, a2a_recv, (int64_t)per_peer)) { err = "all-to-all callback reported failure"; return 1; }
+        std::fill(off.begin(), off.end(), 0);
+        for (const A2APiece &p : recvs) {
+            if (hipMemcpyAsync(p.ptr, a2a_recv + (size_t)p.peer * per_peer + off[p.peer], p.bytes, hipMemcpyHostToDevice, st) != hipSuccess) { err = "all-to-all H2D failed"; return 1; }
+            off[p.peer] += p.bytes;
+        }
+        return 0;
+    }
     int exchange(double *vec, int F, long long plane, long long inner, long long sloc, int ng, hipStream_t st) override
     {
         const size_t w = sizeof(double) * (size_t)ng * inner;     // bytes per field per side

@@ -69,6 +69,7 @@ class HostRing:
         self.errors = []
         self._ex = klib.EXCHANGE_FN(self._exchange)
         self._ar = klib.ALLREDUCE_FN(self._allreduce)
+        self._a2a = klib.ALLTOALL_FN(self._alltoall)
 
     def _view(self, ptr, n):
         return self.torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(n,)))
@@ -103,11 +104,34 @@ class HostRing:
             self.errors.append(repr(e))
             return 1
 
+    def _alltoall(self, ctx, send, recv, bytes_per_peer):
+        """block q of `send` -> rank q, block r of `recv` <- rank r (point-to-point pairs: works on every backend)"""
+        try:
+            n = int(bytes_per_peer)
+            d, g = self.dist, self.group
+            to_global = (lambda r: d.get_global_rank(g, r)) if g is not None else (lambda r: r)
+            sb = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(n * self.size,))
+            rb = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(n * self.size,))
+            t = self.torch.from_numpy
+            rb[self.rank * n:(self.rank + 1) * n] = sb[self.rank * n:(self.rank + 1) * n]
+            reqs = []
+            for q in range(self.size):
+                if q != self.rank:
+                    reqs.append(d.isend(t(sb[q * n:(q + 1) * n]), to_global(q), group=g, tag=7))
+                    reqs.append(d.irecv(t(rb[q * n:(q + 1) * n]), to_global(q), group=g, tag=7))
+            for r in reqs:
+                r.wait()
+            return 0
+        except Exception as e:            # never let an exception cross the C boundary
+            self.errors.append(repr(e))
+            return 1
+
     def cdist(self, device=0):
         d = klib.CDist()
         d.rank, d.size, d.transport, d.device = self.rank, self.size, 2, device
         d.nccl_id = None
         d.exchange, d.allreduce, d.ctx = self._ex, self._ar, None
+        d.alltoall = self._a2a
         return d
 
 
@@ -161,6 +185,35 @@ def reduction_selftest(ks, cfg, rank, size, tol=1e-12):
     want = sum((1000.0 + 7.0 * r) * nloc for r in range(size))
     got = ks.count_worms()
     return bool(abs(got - want) <= tol * want)
+
+
+def spectral_selftest(ks, cfg, rank, size, shift=2.0, tol=2e-3):
+    """End-to-end check of the slab-distributed spectral solver (all-to-all transposes): on a UNIFORM state the constant-
+    coefficient operator it inverts IS the Jacobian, so A (M^-1 v) must give v back (to fp32 accuracy) for a smooth v.  True where
+    the handle has no spectral solver (nothing to check)."""
+    dim = cfg.dim
+    if dim != 2:
+        return True
+    lo, hi = slab_range(cfg.n[1], rank, size)
+    nx, ny = cfg.n[0], cfg.n[1]
+    nloc = (hi - lo) * nx
+    ks.set_state(np.concatenate([np.full(nloc, 9000.0)] + [np.full(nloc, 9000.0 * cfg.lig_s[l] / cfg.lig_gamma[l]) for l in range(cfg.nlig)]))
+    x = np.arange(nx)[None, :] / nx
+    y = np.arange(lo, hi)[:, None] / ny
+    planes = []
+    for c in range(cfg.F):
+        planes.append((np.cos(2 * np.pi * (3 * x + (2 + c) * y)) + 0.5 * np.sin(2 * np.pi * ((5 + c) * x - 7 * y)) + 0.25).reshape(-1))
+    v = np.concatenate(planes)
+    try:
+        z = ks.spectral_apply(shift, v)
+    except klib.KSFDError as e:
+        if e.code == klib.EINVAL:
+            return True
+        raise
+    r = shift * z - ks.jvp(z) - v
+    # fp32 transforms: the rounding of z (6e-8 relative, white) comes back multiplied by the stiffness of A (~1e3 at the grid
+    # scale), i.e. ~1e-4 of v; a misplaced piece of a transpose gives O(1)
+    return bool(np.linalg.norm(r) <= tol * np.linalg.norm(v))
 
 
 def _agree(ok, g, device):
@@ -226,6 +279,15 @@ def open_handle(cfg, rank, size, device, transport='auto', group=None, host_grou
                 ok = _agree(red_ok(), g, device)
                 why = '' if ok else 'RCCL all-reduce self-test failed'
         if ok:
+            # 5. the slab-distributed spectral solver (all-to-all): switched off on every rank if its check fails anywhere
+            def spec_ok():
+                try:
+                    return spectral_selftest(ks, cfg, rank, size)
+                except Exception:         # noqa: BLE001
+                    return False
+            ks.spectral_distributed = _agree(spec_ok(), g, device)
+            if not ks.spectral_distributed:
+                ks.set_spectral_params(enable=0)
             ks.transport_name, ks.rccl_error = 'rccl', None
             return ks, d
         if ks is not None:

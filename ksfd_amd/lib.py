@@ -32,12 +32,13 @@ class KSFDError(RuntimeError):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class CDist(C.Structure):
     _fields_ = [('rank', C.c_int32), ('size', C.c_int32), ('transport', C.c_int32), ('device', C.c_int32),
                 ('nccl_id', C.c_void_p), ('exchange', EXCHANGE_FN), ('allreduce', ALLREDUCE_FN),
-                ('ctx', C.c_void_p)]
+                ('ctx', C.c_void_p), ('alltoall', ALLTOALL_FN)]
 
 
 class StepOpts(C.Structure):

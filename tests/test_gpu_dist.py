@@ -162,3 +162,60 @@ def test_solver_main_on_two_ranks_matches_one_rank(tmp_path):
     both = np.concatenate([parts[0]['data'][25], parts[1]['data'][25]], axis=2)      # (dof, nx, ny): slabs along y
     assert both.shape == one['data'][25].shape
     assert rel_l2(both, one['data'][25]) < 1e-8
+
+
+def _spectral_worker(rank, size, port, shape, nlig, outfile):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        from ksfd_amd import lib as klib
+        from ksfd_amd.dist import open_handle, local_slab, gather_slabs
+        L = tuple(n * 4.0 / 1536 for n in shape)
+        if nlig == 3:          # two ligands sharing a group + a repellent: F = 4, two complex pairs
+            cfg = ProblemConfig(dim=2, n=shape, L=L, lig_group=[0, 0, 1], lig_w=[1.0, 0.5, 1.0], lig_s=[0.01, 0.02, 0.001],
+                                lig_gamma=[0.01, 0.03, 0.001], lig_D=[1e-6, 3e-6, 1e-5], grp_alpha=[1500.0, 1500.0], grp_beta=[5.56e-4, -5.56e-4])
+        else:
+            cfg = ProblemConfig.standard(2, shape, L=L, nlig=nlig)
+        rng = np.random.default_rng(3)
+        N = cfg.N
+        rho = 9000 + 90 * rng.standard_normal(N)
+        u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1 + 0.01 * rng.standard_normal(N)) for l in range(nlig)])
+        v = rng.standard_normal(cfg.F * N)
+        ks, keep = open_handle(cfg, rank, size, 0, transport='host')
+        mine = lambda a: local_slab(a, cfg, rank, size)
+        got = {}
+        from ksfd_amd.dist import spectral_selftest
+        assert spectral_selftest(ks, cfg, rank, size)             # the check open_handle runs on the RCCL transport
+        ks.set_state(mine(u))
+        got['spec'] = gather_slabs(ks.spectral_apply(3.0, mine(v)), cfg)
+        opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=4)
+        t, h, st, rc = ks.step(0.0, 0.3, opts)
+        got['pc'] = np.float64(st.pc_used)
+        got['its'] = np.float64(st.linear_its)
+        got['state'] = gather_slabs(ks.get_state(), cfg)
+        ks.close()
+        if rank == 0:
+            one = klib.KSFDHip(cfg)
+            one.set_state(u)
+            ref = {'spec': one.spectral_apply(3.0, v)}
+            t, h, st1, rc = one.step(0.0, 0.3, opts)
+            ref['state'], ref['its'] = one.get_state(), np.float64(st1.linear_its)
+            one.close()
+            np.savez(outfile, **{'got_' + k: np.asarray(got[k]) for k in got}, **{'ref_' + k: np.asarray(ref[k]) for k in ref})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('size,shape,nlig', [(2, (64, 64), 1), (4, (128, 64), 2), (2, (32, 256), 3)])
+def test_slab_distributed_spectral_solver_matches_single_rank(size, shape, nlig, tmp_path):
+    """the y-transforms of the spectral preconditioner across slab ranks (all-to-all transposes, columns of {kx, -kx} pairs kept on
+    one rank): same operator as on one rank (fp32 FFTs: summation order differs, 1e-5), and a step solved with it is the single-rank
+    step to the solver tolerance"""
+    outfile = str(tmp_path / 'result.npz')
+    mp.spawn(_spectral_worker, args=(size, _free_port(), shape, nlig, outfile), nprocs=size, join=True)
+    z = np.load(outfile)
+    assert int(z['got_pc']) & 8                                   # the spectral solver really ran on the slabs
+    assert rel_l2(z['got_spec'], z['ref_spec']) < 1e-5
+    assert rel_l2(z['got_state'], z['ref_state']) < 1e-9
+    assert z['got_its'] <= z['ref_its'] + 4

@@ -43,6 +43,31 @@ def _numpy_spectral(cfg, u, shift, v):
     return np.real(np.fft.ifft2(np.array(zs))).reshape(-1)
 
 
+def _lu_step(cfg, u, h, atol=0.01, rtol=1e-6):
+    """one RA34PW2 step with the oracle's operators and an exact SPARSE LU of shift*I - J (the oracle's own rosw_step(solver='lu')
+    factorises densely: minutes at 64^2); returns (unew, wrms)"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    o = ko.Oracle(cfg)
+    At, Gi, bt, b2t, asum = ko.tableau()
+    gam = 1.0 / Gi[0, 0]
+    F, N = cfg.F, cfg.N
+    to_vec = lambda a: a.reshape(F, N).T.reshape(-1)
+    to_soa = lambda x: x.reshape(N, F).T.reshape(-1)
+    ug = o.groom(u)
+    rp, col, val = o.jacobian_csr(ug)
+    J = sp.csr_matrix((val, col, rp), shape=(F * N, F * N))
+    lu = spla.splu((sp.identity(F * N, format='csc') / (gam * h) - J).tocsc())
+    Y = []
+    for i in range(4):
+        Z = ug + sum(At[i, j] * Y[j] for j in range(i))
+        Zdot = sum((Gi[i, j] / h) * Y[j] for j in range(i)) if i else 0.0
+        Y.append(to_soa(lu.solve(to_vec(o.rhs(Z) - Zdot))))
+    unew = ug + sum(bt[j] * Y[j] for j in range(4))
+    err = sum((b2t[j] - bt[j]) * Y[j] for j in range(4))
+    return unew, ko.wrms(unew, err, atol, rtol)
+
+
 def _three_ligands(shape, L):
     """two ligands sharing group 0 (weights) + a repellent in its own group: F = 4 -> two complex pairs"""
     return ProblemConfig(dim=2, n=shape, L=L, lig_group=[0, 0, 1], lig_w=[1.0, 0.5, 1.0], lig_s=[0.01, 0.02, 0.001],
@@ -90,8 +115,7 @@ def test_step_with_spectral_preconditioner_vs_oracle_lu(shape, nlig, h, pc):
     L = tuple(n * 4.0 / 1536 for n in shape)
     cfg = _three_ligands(shape, L) if nlig == 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
     u = _state(cfg, 7)
-    o = ko.Oracle(cfg)
-    un, err, wr, _ = o.rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    un, wr = _lu_step(cfg, u, h)
     k = klib.KSFDHip(cfg)
     k.set_state(u)
     t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-12, pc_type=pc))
@@ -113,8 +137,7 @@ def test_automatic_choice_leaves_the_spectral_preconditioner_when_coefficients_v
     rho = (800.0 + 24000.0 * bump).reshape(-1) * (1 + 0.01 * rng.standard_normal(cfg.N))
     u = np.concatenate([rho, rho * 1.0])
     h = 2.0
-    o = ko.Oracle(cfg)
-    un, err, wr, _ = o.rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    un, wr = _lu_step(cfg, u, h)
     k = klib.KSFDHip(cfg)
     k.set_state(u)
     opts = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
