@@ -285,7 +285,8 @@ def main():
                              'grid': [args.n] * args.dim, 'fields': cfg.F, 'ksp_rtol': float(o.ksp_rtol), 'pc_type': int(o.pc_type),
                              't_star': t_star, 'h_star': h_star, 'window': args.window, 't_end_of_window': t_last,
                              'parallelism': 'slab%d' % world, 'transport': getattr(ks, 'transport_name', 'none'),
-                             'rccl_error': getattr(ks, 'rccl_error', None)}, **tal.summary()),
+                             'rccl_error': getattr(ks, 'rccl_error', None),
+                             'spectral_distributed': getattr(ks, 'spectral_distributed', None)}, **tal.summary()),
             'roofline': {'bound': 'hbm', 'kernel': dom,
                          # `achieved`/`frac`: ALGORITHMIC bytes per launch (Jacobian action 24*F*N) / HIP-event time per launch
                          'achieved': gbs(alg_bytes), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs(alg_bytes) / HBM_PEAK_GBS,

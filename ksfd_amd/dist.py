@@ -304,6 +304,10 @@ def open_handle(cfg, rank, size, device, transport='auto', group=None, host_grou
     ring = HostRing(g)
     ks = klib.KSFDHip(cfg, ring.cdist(device))
     ks._ring = ring
+    # through host staging the all-to-all transposes of the spectral solver cross PCIe twice: never pick it automatically here
+    # (pc_type 4 still forces it: that is how the tests exercise the distributed transforms on one GPU)
+    ks.set_spectral_params(enable=0)
+    ks.spectral_distributed = False
     ks.transport_name = 'host-fallback' if transport == 'auto' else 'host'
     ks.rccl_error = why or None
     return ks, ring
