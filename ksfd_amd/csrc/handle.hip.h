@@ -30,7 +30,7 @@ struct MGLevel {
 
 // spectral preconditioner (spectral.hip.h / spectral_host.hip.h)
 struct SpecState {
-    bool ok = false, means_valid = false;
+    bool ok = false, means_valid = false, tile_major = false;
     KFFTPlan px, py;
     int rb = 0, npair = 0, nyp = 0;
     size_t lds_rows = 0, lds_cols = 0;

@@ -282,7 +282,10 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
     }
     __syncthreads();
     kspec_fft_fwd(PX, kspec_lds, sstride, rb, tw);
-    if (ntiles < 0) {              // timing experiment only (KSFD_SPEC_DIAG bit 3): contiguous tile-major store
+    if (ntiles < 0) {
+        // one rank: TILE-MAJOR store Wt[pair][tile][pos][r] -- one contiguous run per block (the transposed store below writes
+        // 32-B segments, 151 -> 95 us); the column kernel gathers its columns from the tiles instead (strided READS are cheap: the
+        // four positions of a 128-B line belong to blocks that run side by side on one XCD)
         kcf *Wt = W + ((long long)p * (-ntiles) + y0 / rb) * nx * rb;
         for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
             const int j = idx >> lg_rb, r = idx & (rb - 1);
@@ -359,15 +362,17 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
 // Column storage: column (pair p, local position jl) consists of `ny >> lg_pl` pieces of 2^lg_pl elements, `pstride` elements
 // apart (one piece per slab rank after the all-to-all; a single piece of ny elements on one rank); pairtab[block] =
 // (jlA, jlB, kxA, self): the two local positions the block owns, the wavenumber of the first, and whether both are self-paired.
+// lg_rb >= 0 (one rank): the columns are READ from the tile-major array Wt[pair][tile][pos][r] the row kernel wrote
+// (r = y mod 2^lg_rb) and written to W[pair][pos][y] for the inverse row kernel; lg_rb < 0: in place in W.
 template <int NL>
-__global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ tw,
+__global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ Wt, int lg_rb, const kcf *__restrict__ tw,
                                                    const int4 *__restrict__ pairtab, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
     constexpr int F = NL + 1, npair = (F + 1) / 2;
     const int ny = PY.n;
-    const int4 pt = pairtab[blockIdx.x];
+    const int4 pt = pairtab[kspec_tile(blockIdx.x, gridDim.x)];       // consecutive pairs (= neighbouring positions) on one XCD
     const bool self = pt.w != 0;                                // kx = 0 and kx = nx/2 are their own partners
     const int jA = pt.x, jB = pt.y, kxA = pt.z, kxB = self ? pt.w - 1 : pt.z;     // lx is even: lx[-kx] = lx[kx]
     const int sstride = ny + (ny >> 4) + 1;
@@ -385,7 +390,8 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
             const int idx = base + u * blockDim.x + threadIdx.x;
             if (idx < nseq * half) {
                 const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
-                t[u] = *reinterpret_cast<const float4 *>(colat(s, y));
+                t[u] = lg_rb >= 0 ? *reinterpret_cast<const float4 *>(Wt + ((((long long)(s >> 1) * (ny >> lg_rb) + (y >> lg_rb)) * nxl + ((s & 1) ? jB : jA)) << lg_rb) + (y & ((1 << lg_rb) - 1)))
+                                   : *reinterpret_cast<const float4 *>(colat(s, y));
             }
         }
 #pragma unroll

@@ -110,11 +110,15 @@ static void spec_build(ksfd_handle *h)
         if (kx == 0) pairs.push_back(make_int4(local_index(posx[0]), local_index(posx[nx / 2]), 0, nx / 2 + 1));     // the two self-paired columns share a block
         else if (kx != nx / 2) pairs.push_back(make_int4(local_index(j), local_index(jm), kx, 0));
     }
+    // neighbouring blocks of the column kernel should own neighbouring positions (they share the 128-B lines of the tile-major
+    // array, and of the transposed one through the inverse row kernel's tiles)
+    std::sort(pairs.begin(), pairs.end(), [](const int4 &a, const int4 &b) { return a.x < b.x; });
     S.nblk_cols = (int)pairs.size();
     if (S.nblk_cols != S.nxl / 2) return;                            // (cannot happen for P in {1, 2, 4, 8}: the digit pairs keep kx and -kx together)
     const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nyl;
     S.nyp = (int)nyl;
-    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || (P > 1 && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
+    S.tile_major = P == 1 && rb >= 2 && !getenv("KSFD_SPEC_TRANSPOSED");
+    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || ((P > 1 || S.tile_major) && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
         !spec_upload(&S.twx, twiddles(S.px.n)) || !spec_upload(&S.twy, twiddles(S.py.n)) ||
         !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) || !spec_upload(&S.pairtab, pairs) ||
         !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1]))) { hipGetLastError(); spec_free(h); return; }
@@ -176,7 +180,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     const int ntiles = (int)(G.sloc / S.rb);
     const long long goff = (long long)G.ng * G.inner;                // the row kernels address owned rows only
     const long long ny_glob = h->cfg.n[1];
-    // timing-only diagnostics (wrong results): KSFD_SPEC_DIAG bit0/1/2 = skip the FFT stages of the rows-fwd / cols / rows-inv kernel, bit3 = rows-fwd stores tile-major (contiguous)
+    // timing-only diagnostics (wrong results): KSFD_SPEC_DIAG bit0/1/2 = skip the FFT stages of the rows-fwd / cols / rows-inv kernel
     static const int diag = getenv("KSFD_SPEC_DIAG") ? atoi(getenv("KSFD_SPEC_DIAG")) : 0;
     KFFTPlan px_f = S.px, py_c = S.py, px_i = S.px;
     if (diag & 1) px_f.nstage = 0;
@@ -189,8 +193,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
         Scope sc(h, KC_SPECTRAL, (v32 ? 4.0 : 8.0) * fn + pn, 8.0 * fn);        // read v | write W
-        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v32 + goff, G.plane, S.W, (const kcf *)S.twx);
-        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, (diag & 8) ? -ntiles : ntiles, G.F, v + goff, G.plane, S.W, (const kcf *)S.twx);
+        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v32 + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx);
+        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx);
     }
     kcf *Wc = S.W;
     if (h->size > 1) {                                                // rows of everybody's columns -> whole columns of mine
@@ -201,7 +205,9 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     {
         Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // work array in place
         const long long pstride = (long long)S.npair * S.nxl << S.lg_pl;
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec_cols<NL>), dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)S.twy,
+        int lg_rb = 0;
+        while ((1 << lg_rb) < S.rb) lg_rb++;
+        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec_cols<NL>), dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy,
                            (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y));
     }
     if (h->size > 1) {
