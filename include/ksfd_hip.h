@@ -241,7 +241,7 @@ int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target, doub
  * (grid means of rho*G_rho, rho*G_Ul; the 4th-order star's exact symbol), three hand-written FFT kernels (csrc/spectral.hip.h).
  * _apply is the parity/test entry (host vectors; KSFD_EINVAL where the handle cannot use it: 1-D/3-D, several ranks, extents
  * that are not powers of two in 32..16384).  _params: stiffness h*gamma*lambda_max(diffusion) from which pc_type 2 prefers it
- * (default 1; <= 0 keeps) and enable (0 = never pick it automatically, 1 = default, < 0 keeps). */
+ * (default 0.3; <= 0 keeps) and enable (0 = never pick it automatically, 1 = default, < 0 keeps). */
 int ksfd_spectral_apply(ksfd_handle *h, double shift, const double *v_host, double *out_host, int32_t layout);
 int ksfd_set_spectral_params(ksfd_handle *h, double from_stiffness, int32_t enable);
 

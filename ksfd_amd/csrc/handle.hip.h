@@ -74,7 +74,7 @@ struct ksfd_handle {
                         long long nsteps, spec_bad_until; int spec_backoff; };
     SpecState spec;
     long long nsteps = 0;                   // ksfd_step calls so far
-    double spec_from = 1.0;                 // stiffness above which pc_type 2 prefers the spectral preconditioner (below: plain GMRES / low-degree polynomial)
+    double spec_from = 0.3;                 // stiffness above which pc_type 2 prefers the spectral preconditioner (below: plain GMRES / low-degree polynomial)
     SolverMemo ckpt_memo;
     bool ckpt_valid = false;
     double *Gb = nullptr, *dGb = nullptr;   // generic-path scratch planes
@@ -97,7 +97,7 @@ struct ksfd_handle {
 
     // tuning
     int use_fused = 1;
-    int yseg = 20;        // rows per wave segment, RHS kernel (tools/yseg_sweep.py at 4096^2: 0.284 ms vs 0.305 at 32+)
+    int yseg = 48;        // rows per wave segment, RHS kernel (tools/kbench.py at 4096^2 with the hand-rolled log/exp: 8: 0.253, 16: 0.222, 32: 0.198, 64: 0.190 ms)
     int yseg_jvp = 16;    // same for the Jacobian-action kernels
     int zseg = 32;        // planes per wave segment, 3-D z-marching kernel
 

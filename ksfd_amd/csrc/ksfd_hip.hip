@@ -156,6 +156,9 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         alloc_d(h, &h->flat, (int64_t)std::max(G.F, 3) * G.nloc) ||
         alloc_d(h, &h->part, (int64_t)(2 * KSFD_MAXDOT + 4) * 4096))
         CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
+    // flexible-GMRES / spectral-fallback basis: allocated here when the device has room (the sizing above counted it), so that no step
+    // pays a multi-GB hipMalloc; if it does not fit now it is tried again on first use
+    if (hipMalloc((void **)&h->Zb, sizeof(double) * (size_t)h->restart_alloc * (size_t)h->vlen) != hipSuccess) { h->Zb = nullptr; hipGetLastError(); }
     hipMemsetAsync(h->Y, 0, sizeof(double) * (size_t)(4 * h->vlen), h->st);
     hipMemsetAsync(h->V, 0, sizeof(double) * (size_t)((h->restart_alloc + 1) * h->vlen), h->st);
     if (hipHostMalloc((void **)&h->hres, sizeof(double) * 128 + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) CFAIL(KSFD_ENOMEM, "hipHostMalloc failed");

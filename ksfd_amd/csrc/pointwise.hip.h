@@ -13,10 +13,62 @@
 // Derivatives.groom (KSFD/ksfdsym.py:888-900): x = max(x, lo), NaN -> lo.  One compare covers both.
 __device__ __forceinline__ double ksfd_clamp(double x, double lo) { return !(x >= lo) ? lo : x; }
 
+// fp64 log / exp for the free energy.  The RHS kernel is bound by these (two logs and a tanh per point): the library versions
+// cost ~60-70 instructions each with their special-case handling; here the arguments are known to be positive, finite and far
+// from the subnormal range (inputs are clamped to >= 1e-7 and NaN-scrubbed, alpha + sum w U > 0), so the classical reductions
+// suffice.  Both are faithful to < 1 ulp (fdlibm's polynomials and error bounds: e_log.c / e_exp.c, Sun Microsystems 1993).
+__device__ __forceinline__ double ksfd_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);                 // v_rcp_f64: ~1e-8 relative
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;                                           // < 1 ulp for the normal-range arguments used here
+}
+__device__ __forceinline__ double ksfd_div(double a, double x)
+{
+    const double r = ksfd_rcp(x);
+    const double q = a * r;
+    return fma(fma(-x, q, a), r, q);                    // one residual correction: correctly rounded but for rare ties
+}
+// log(x), x > 0 normal
+__device__ __forceinline__ double ksfd_log(double x)
+{
+    // x = 2^k * m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f/(2+f); log(m) = f - hfsq + s*(hfsq + R(s^2))
+    int k = __builtin_amdgcn_frexp_exp(x);              // x = mant * 2^k, mant in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = ksfd_div(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+// exp(x) for |x| < 700
+__device__ __forceinline__ double ksfd_exp(double x)
+{
+    const double kf = rint(x * 1.44269504088896338700e+00);
+    const double hi = fma(-kf, 6.93147180369123816490e-01, x), lo = kf * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * fma(t, fma(t, fma(t, fma(t, 4.13813679705723846039e-08, -1.65339022054652515390e-06), 6.61375632143793436117e-05),
+                                        -2.77777777770155933842e-03), 1.66666666666666019037e-01);
+    const double y = 1.0 - ((lo - ksfd_div(r * c, 2.0 - c)) - hi);
+    return ldexp(y, (int)kf);
+}
+
 // Free energy G(rho,U) = sum_g -beta_g log(alpha_g + sum_l w_gl U_gl) + Vcap(rho) + s2 log(rho)
 // (KSFD/ksfdsym.py:983-990, ksfdligand.py:527-547, ksfdsoln.py:147-161) and, for the Jacobian
 // action, its partials G_rho and G_Ul (closed forms: SURVEY.md section 0).
 // NL is a compile-time ligand count so U[]/GU[] stay in registers.
+// The cap needs tanh(y) + 1 and 1 - tanh(y)^2 only: with t = exp(-2|y|), tanh(|y|) + 1 = 2/(1+t), tanh(-|y|) + 1 = 2t/(1+t) and
+// 1 - tanh^2 = 4t/(1+t)^2 -- one exp and one reciprocal, and no cancellation anywhere (rho far below rhomax gives t ~ 1e-8:
+// "tanh + 1" formed from a rounded tanh would keep 8 digits).
 template <int NL, bool DERIV>
 __device__ __forceinline__ void ksfd_G(const KPhys &P, double rho, const double (&U)[NL], double &G,
                                        double &Grho, double (&GU)[NL])
@@ -26,25 +78,37 @@ __device__ __forceinline__ void ksfd_G(const KPhys &P, double rho, const double 
         double s = P.grp_alpha[q];
 #pragma unroll
         for (int l = 0; l < NL; l++) s += (P.lig_group[l] == q) ? P.lig_w[l] * U[l] : 0.0;
-        g -= P.grp_beta[q] * log(s);
+        g -= P.grp_beta[q] * ksfd_log(s);
         if (DERIV) {
-            double nb = -P.grp_beta[q] / s;
+            double nb = -P.grp_beta[q] * ksfd_rcp(s);
 #pragma unroll
             for (int l = 0; l < NL; l++) GU[l] = (P.lig_group[l] == q) ? nb * P.lig_w[l] : GU[l];
         }
     }
-    double th = tanh((rho - P.rhomax) * P.inv_cushion);
+    const double y = (rho - P.rhomax) * P.inv_cushion;
+    const double ay = fabs(y);
+    double thp1, sech2;                          // tanh(y) + 1, 1 - tanh(y)^2
+    if (ay > 19.5) {                             // exp(-39) < 2^-56: tanh(|y|) rounds to 1 (lanes diverge only at such aggregates)
+        thp1 = y > 0.0 ? 2.0 : 2.0 * ksfd_exp(-2.0 * ay);
+        sech2 = 0.0;
+        if (DERIV && !(y > 0.0)) sech2 = 2.0 * thp1;
+    } else {
+        const double t = ksfd_exp(-2.0 * ay);
+        const double r = ksfd_rcp(1.0 + t);
+        thp1 = y > 0.0 ? 2.0 * r : 2.0 * t * r;
+        sech2 = 4.0 * t * r * r;
+    }
     double cap, dcap;
     if (P.cap_kind == 1) {                        // witch
         double r = rho * P.inv_rhomax;
-        cap = P.ms * (th + 1.0) * r;
-        dcap = P.ms * ((1.0 - th * th) * r * P.inv_cushion + (th + 1.0) * P.inv_rhomax);
+        cap = P.ms * thp1 * r;
+        dcap = P.ms * (sech2 * r * P.inv_cushion + thp1 * P.inv_rhomax);
     } else {                                      // tophat
-        cap = P.ms * (th + 1.0);
-        dcap = P.ms * (1.0 - th * th) * P.inv_cushion;
+        cap = P.ms * thp1;
+        dcap = P.ms * sech2 * P.inv_cushion;
     }
-    G = g + cap + P.s2 * log(rho);
-    if (DERIV) Grho = P.s2 / rho + dcap;
+    G = g + cap + P.s2 * ksfd_log(rho);
+    if (DERIV) Grho = P.s2 * ksfd_rcp(rho) + dcap;
 }
 
 // ---------------------------------------------------------------------------------------------
