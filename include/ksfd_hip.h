@@ -224,6 +224,7 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * bit11 set = fetch reduction results with a stream synchronisation + copy instead of spinning on a flag the
  * reduction kernel raises in mapped host memory;
  * bit12 set = multigrid smoother as separate kernels instead of inside the Jacobian-action epilogues;
+ * bit14 set = spectral stage solves start from zero instead of from the span of the earlier stage solutions of the step;
  * bit13 set = 3-D RHS through the generic one-thread-per-point stencil pass instead of the z-marching strip kernel;
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);

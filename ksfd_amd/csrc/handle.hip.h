@@ -70,6 +70,8 @@ struct ksfd_handle {
     double *u = nullptr, *usave = nullptr, *Z = nullptr, *bvec = nullptr, *Y = nullptr, *V = nullptr;
     double *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *errv = nullptr;
     double *ckpt = nullptr;                 // ksfd_checkpoint slot (allocated on first save)
+    double *bstore = nullptr;               // right-hand sides of stages 0..2 of the current step (initial guesses of the spectral solves)
+    bool spec_guess = true;
     struct SolverMemo { double lamJ; int lam_age, lam_period; double mg_shift_floor; int sf_dir, sf_hold; bool sf_tried_down; double sf_prev_its, sf_prev_floor;
                         long long nsteps, spec_bad_until; int spec_backoff; };
     SpecState spec;

@@ -420,7 +420,10 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
 // flexible GMRES with the same preconditioner, and if that fails too the caller falls back to the V cycle.
 // bnorm2 >= 0: ||b||^2 if the caller already has it (RHS kernel epilogue), else it is computed here.
 // ------------------------------------------------------------------------------------------------
-static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, const ksfd_step_opts *o, LinStats *ls, double bnorm2, int gmres_cap)
+// guess != NULL: the first sweep starts from x0 = sum_j c_j Y_j (earlier stage solutions of the same step, A Y_j = b_j):
+//   x = x0 + M^-1 (b - sum_j c_j b_j)   -- no extra Jacobian action, the vectors ride in the row kernels of the application
+static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, const ksfd_step_opts *o, LinStats *ls, double bnorm2, int gmres_cap,
+                      const SpecGuess *guess = nullptr)
 {
     int rc;
     const int64_t vs = h->vlen;
@@ -444,7 +447,7 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
     const bool fused = fused_ok(h);
     bool slow = false;
     for (int k = 0; k < maxit; k++) {
-        if (k == 0) rc = spec_apply(h, shift, b, x);
+        if (k == 0) rc = spec_apply(h, shift, b, x, nullptr, nullptr, guess);
         else rc = fused ? spec_apply(h, shift, nullptr, x, x, r32) : spec_apply(h, shift, r, x, x);
         if (rc) return rc;
         if (h->size > 1 && (rc = halo(h, x))) return rc;                                     // the spectral application wrote owned rows only

@@ -35,7 +35,7 @@ extern "C" void ksfd_destroy(ksfd_handle *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->st) hipStreamSynchronize(h->st);
-    double *bufs[] = { h->ckpt, h->Zb, h->pvec, h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
+    double *bufs[] = { h->bstore, h->ckpt, h->Zb, h->pvec, h->coef, h->u, h->usave, h->Z, h->bvec, h->Y, h->V, h->t1, h->t2, h->t3, h->errv, h->Gb, h->dGb, h->flat, h->part, h->dres };
     for (double *b : bufs) if (b) hipFree(b);
     for (int s = 0; s < 4; s++) for (int c = 0; c <= KSFD_MAXL; c++) if (h->src[s][c]) hipFree(h->src[s][c]);
     if (h->coef32) hipFree(h->coef32);
@@ -645,9 +645,17 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const bool fuse_stage = (fused_ok(h) || (strip3d_ok(h) && h->rhs3d_strip)) && h->P.nlig <= 4 && h->fuse_stage;
         const int its_before = st.linear_its;
         bool spec_failed = false;
+        // Initial guesses for the spectral stage solves from the earlier stages of the step (A Y_j = b_j is known): the right-hand
+        // sides of a step are nearly dependent -- b_1 = c b_0 to ~1e-3, later ones to a few per cent (CPU experiment with the oracle)
+        // -- so x0 = sum c_j Y_j, c = argmin ||b_i - sum c_j b_j||, starts the defect correction 1-3 digits ahead for one small
+        // multi-dot.  The b_j are kept in bstore (three vectors, allocated on first use); gb = their Gram matrix.
+        bool guess_on = use_spec && fuse_stage && h->spec_guess;
+        if (guess_on && !h->bstore && alloc_d(h, &h->bstore, 3 * vs)) { h->bstore = nullptr; guess_on = false; h->err.clear(); }
+        double gb[4][4];
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
             double bnorm2 = -1.0;                 // ||b||^2 when the RHS kernel's epilogue delivered it
+            double *bcur = (guess_on && i < 3) ? h->bstore + (int64_t)i * vs : h->bvec;
             if (fuse_stage) {
                 // stage argument and Zdot term folded into the RHS kernel (no Z vector, no separate passes)
                 KComb cmb = KComb{};
@@ -656,8 +664,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                     if (h->Ginv[i][j] != 0.0) { cmb.yout[cmb.nout] = h->Y + (int64_t)j * vs; cmb.aout[cmb.nout++] = -h->Ginv[i][j] / hh; }
                 }
                 if (i > 0 && (rc = halo(h, h->Y + (int64_t)(i - 1) * vs))) break;     // ghosts of the newest stage vector (earlier ones done)
-                if ((rc = op_rhs(h, h->u, i, h->bvec, &cmb, use_spec))) break;
-                if (use_spec) bnorm2 = h->hres[0];
+                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, use_spec && !(guess_on && i > 0)))) break;
+                if (use_spec && !(guess_on && i > 0)) bnorm2 = h->hres[0];
             } else {
             if (i > 0) {
                 const double *xs[5]; double a[5]; int nt = 0;
@@ -679,15 +687,43 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             LinStats ls;
             if (use_spec) {
+                SpecGuess sg;
+                sg.n = 0;
+                if (guess_on) {
+                    if (i == 0) gb[0][0] = bnorm2;
+                    else {
+                        // <b_i, b_j> (j < i) and <b_i, b_i> in one pass; least squares on the (ill-conditioned but tiny) Gram system
+                        if ((rc = op_multidot(h, bcur, h->bstore, i))) break;
+                        for (int j = 0; j < i; j++) gb[i][j] = gb[j][i] = h->hres[j];
+                        gb[i][i] = bnorm2 = h->hres[i];
+                        double M[3][4];
+                        for (int a = 0; a < i; a++) { for (int c = 0; c < i; c++) M[a][c] = gb[a][c]; M[a][i] = gb[i][a]; M[a][a] *= 1.0 + 1e-13; }
+                        bool okls = true;
+                        for (int c = 0; c < i && okls; c++) {              // Gaussian elimination with partial pivoting
+                            int pv = c;
+                            for (int a = c + 1; a < i; a++) if (fabs(M[a][c]) > fabs(M[pv][c])) pv = a;
+                            if (!(fabs(M[pv][c]) > 0.0)) { okls = false; break; }
+                            for (int q = 0; q <= i; q++) std::swap(M[c][q], M[pv][q]);
+                            for (int a = c + 1; a < i; a++) { const double f = M[a][c] / M[c][c]; for (int q = c; q <= i; q++) M[a][q] -= f * M[c][q]; }
+                        }
+                        double cf[3] = { 0, 0, 0 };
+                        for (int a = i - 1; a >= 0 && okls; a--) { double t = M[a][i]; for (int q = a + 1; q < i; q++) t -= M[a][q] * cf[q]; cf[a] = t / M[a][a]; }
+                        double pred = gb[i][i];                                // ||b_i - sum c_j b_j||^2 = b.b - 2 c.g + c.G c
+                        for (int a = 0; a < i; a++) { pred -= 2.0 * cf[a] * gb[i][a]; for (int c = 0; c < i; c++) pred += cf[a] * cf[c] * gb[a][c]; }
+                        if (okls && pred == pred && pred < 0.09 * gb[i][i]) {
+                            for (int j = 0; j < i; j++) if (cf[j] != 0.0) { sg.Y[sg.n] = h->Y + (int64_t)j * vs; sg.b[sg.n] = h->bstore + (int64_t)j * vs; sg.c[sg.n++] = cf[j]; }
+                        }
+                    }
+                }
                 // defect correction with M^-1 (no Krylov vectors), flexible GMRES for the rest if it contracts slowly; the attempt
                 // is capped so that a state it does not suit costs little, then the V cycle / plain GMRES takes over
-                rc = spec_solve(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, bnorm2, opts->pc_type == 2 ? 40 : 0);
+                rc = spec_solve(h, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls, bnorm2, opts->pc_type == 2 ? 40 : 0, sg.n ? &sg : nullptr);
                 st.pc_used |= 8;
                 if (rc == KSFD_ELINEAR && opts->pc_type == 2) {
                     spec_failed = true;
                     st.linear_its += ls.its;
                     const bool mg_here = h->mg_ok && stiff > 0.3;
-                    rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, mg_here ? 1 : 0);
+                    rc = gmres(h, h->u, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls, mg_here ? 1 : 0);
                     st.pc_used |= mg_here ? 2 : 1;
                 }
             } else {
@@ -700,7 +736,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
                 // unpreconditioned GMRES ran out of iterations: the multigrid-preconditioned solve of the same system
                 // is the remedy (the stiffness estimate above only knows the diffusion part of J)
-                rc = gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, 1);
+                rc = gmres(h, h->u, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls, 1);
                 st.pc_used |= 2;
                 st.linear_its += ls.its;
                 st.ksp_resid = ls.rel;
@@ -897,6 +933,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->fuse_stage = !(use_fused & 1024);
         h->zero_copy = !(use_fused & 2048) && h->hres_dev;
         h->rhs3d_strip = !(use_fused & 8192);
+        h->spec_guess = !(use_fused & 16384);
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

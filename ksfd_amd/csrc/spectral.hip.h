@@ -36,6 +36,13 @@ struct KFFTPlan {
     int radix[KSPEC_MAXSTAGE];     // DIF stage order; prod = n
 };
 
+// a few fp64 vectors with coefficients: added to the input of the forward row kernel / to the output of the inverse one
+struct KSpecLin {
+    int n;
+    const double *p[3];
+    double a[3];
+};
+
 struct KSpecSym {
     int nlig;
     float shift, a_rr, scale, den_floor;
@@ -243,8 +250,9 @@ __device__ __forceinline__ int kspec_tile(int b, int ntiles)
 // TIN: storage type of v (double; float for the defect-correction residual, which only this kernel ever reads)
 template <typename TIN>
 __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* column stride of W */, int rb, int ntiles, int F, const TIN *__restrict__ v, long long plane,
-                                                        kcf *__restrict__ W, const kcf *__restrict__ tw)
+                                                        kcf *__restrict__ W, const kcf *__restrict__ tw, KSpecLin ex)
 {
+    // ex: the transform is taken of v + sum_j ex.a[j] * ex.p[j] (initial guess of the defect correction: b - sum c_j b_j)
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
     const int y0 = kspec_tile(blockIdx.x, ntiles < 0 ? -ntiles : ntiles) * rb;
@@ -267,6 +275,12 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
                 const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
                 a[u] = ksfd_ld2(va + (long long)r * nx + x);
                 if (has_b) b[u] = ksfd_ld2(vb + (long long)r * nx + x);
+                for (int j = 0; j < ex.n; j++) {            // wave-uniform, usually 0
+                    const long long o = (long long)(2 * p) * plane + (long long)(y0 + r) * nx + x;
+                    const double2 ea = ksfd_ld2(ex.p[j] + o);
+                    a[u].x += ex.a[j] * ea.x; a[u].y += ex.a[j] * ea.y;
+                    if (has_b) { const double2 eb = ksfd_ld2(ex.p[j] + o + plane); b[u].x += ex.a[j] * eb.x; b[u].y += ex.a[j] * eb.y; }
+                }
             }
         }
 #pragma unroll
@@ -301,9 +315,9 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
 }
 
 // W[pair][pos][y] -> rows of z (F fp64 planes)
-// xadd != NULL: z = xadd + M^-1 v (xadd may alias z: every element is read and written by the same thread)
+// z = sum_j add.a[j] * add.p[j] + M^-1 v (a p[j] may alias z: every element is read and written by the same thread)
 __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, int rb, int ntiles, int F, const kcf *__restrict__ W,
-                                                        double *z, long long plane, const kcf *__restrict__ tw, const double *xadd)
+                                                        double *z, long long plane, const kcf *__restrict__ tw, KSpecLin add)
 {
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
@@ -332,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
         kspec_stage0_inv_to(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int e, kcf c) {
             const long long o = o0 + (long long)r * nx + e;
             double a = (double)c.x, b = (double)c.y;
-            if (xadd) { a += xadd[o]; if (has_b) b += xadd[o + plane]; }
+            for (int j = 0; j < add.n; j++) { a += add.a[j] * add.p[j][o]; if (has_b) b += add.a[j] * add.p[j][o + plane]; }
             z[o] = a;
             if (has_b) z[o + plane] = b;
         });
@@ -346,10 +360,10 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
         const kcf c0 = row[kspec_pad(x)], c1 = row[kspec_pad(x + 1)];
         const long long o = o0 + (long long)r * nx + x;
         double2 a = make_double2((double)c0.x, (double)c1.x), b = make_double2((double)c0.y, (double)c1.y);
-        if (xadd) {
-            const double2 xa = *reinterpret_cast<const double2 *>(xadd + o);
-            a.x += xa.x; a.y += xa.y;
-            if (has_b) { const double2 xb = *reinterpret_cast<const double2 *>(xadd + o + plane); b.x += xb.x; b.y += xb.y; }
+        for (int j = 0; j < add.n; j++) {
+            const double2 xa = *reinterpret_cast<const double2 *>(add.p[j] + o);
+            a.x += add.a[j] * xa.x; a.y += add.a[j] * xa.y;
+            if (has_b) { const double2 xb = *reinterpret_cast<const double2 *>(add.p[j] + o + plane); b.x += add.a[j] * xb.x; b.y += add.a[j] * xb.y; }
         }
         *reinterpret_cast<double2 *>(z + o) = a;
         if (has_b) *reinterpret_cast<double2 *>(z + o + plane) = b;

@@ -165,7 +165,9 @@ static int spec_means(ksfd_handle *h)
 // z = M^-1 v, M = shift*I - J0 (constant-coefficient part of the frozen Jacobian)
 // xadd != NULL: z = xadd + M^-1 v (one Richardson update without a vector pass of its own)
 // v32 != NULL: the input is that fp32 copy (F planes of floats, same geometry) instead of v
-static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, const double *xadd = nullptr, const float *v32 = nullptr)
+// guess != NULL (with v): z = sum_j c_j Y_j + M^-1 (v - sum_j c_j b_j), the first sweep from an initial guess in span{Y_j}
+struct SpecGuess { int n; const double *Y[3], *b[3]; double c[3]; };
+static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, const double *xadd = nullptr, const float *v32 = nullptr, const SpecGuess *guess = nullptr)
 {
     SpecState &S = h->spec;
     const KGeom &G = h->G;
@@ -179,6 +181,15 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     for (int l = 0; l < h->P.nlig; l++) { Y.a_rU[l] = (float)S.a_rU[l]; Y.s[l] = (float)h->P.lig_s[l]; Y.gam[l] = (float)h->P.lig_gamma[l]; Y.D[l] = (float)h->P.lig_D[l]; }
     const int ntiles = (int)(G.sloc / S.rb);
     const long long goff = (long long)G.ng * G.inner;                // the row kernels address owned rows only
+    KSpecLin ex, add;
+    memset(&ex, 0, sizeof ex); memset(&add, 0, sizeof add);
+    if (xadd) { add.n = 1; add.p[0] = xadd + goff; add.a[0] = 1.0; }
+    if (guess && !v32) {
+        for (int j = 0; j < guess->n && j < 3; j++) {
+            ex.p[ex.n] = guess->b[j] + goff; ex.a[ex.n++] = -guess->c[j];
+            add.p[add.n] = guess->Y[j] + goff; add.a[add.n++] = guess->c[j];
+        }
+    }
     const long long ny_glob = h->cfg.n[1];
     // timing-only diagnostics (wrong results): KSFD_SPEC_DIAG bit0/1/2 = skip the FFT stages of the rows-fwd / cols / rows-inv kernel
     static const int diag = getenv("KSFD_SPEC_DIAG") ? atoi(getenv("KSFD_SPEC_DIAG")) : 0;
@@ -192,9 +203,9 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     if (getenv("KSFD_SPEC_THRC")) thr_cols = atoi(getenv("KSFD_SPEC_THRC"));
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
-        Scope sc(h, KC_SPECTRAL, (v32 ? 4.0 : 8.0) * fn + pn, 8.0 * fn);        // read v | write W
-        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v32 + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx);
-        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx);
+        Scope sc(h, KC_SPECTRAL, (v32 ? 4.0 : 8.0) * fn + 8.0 * ex.n * fn + pn, 8.0 * (1 + ex.n) * fn);        // read v (+ guess vectors) | write W
+        if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v32 + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx, ex);
+        else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx, ex);
     }
     kcf *Wc = S.W;
     if (h->size > 1) {                                                // rows of everybody's columns -> whole columns of mine
@@ -215,8 +226,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         if (h->tr->alltoall(S.a2a_bwd_s, S.a2a_bwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
     }
     {
-        Scope sc(h, KC_SPECTRAL, pn + (xadd ? 16.0 : 8.0) * fn, (xadd ? 16.0 : 8.0) * fn);     // read W (+ x) | write z
-        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)S.W, z + goff, G.plane, (const kcf *)S.twx, xadd ? xadd + goff : (const double *)nullptr);
+        Scope sc(h, KC_SPECTRAL, pn + 8.0 * (1 + add.n) * fn, 8.0 * (1 + add.n) * fn);     // read W (+ x / guess vectors) | write z
+        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)S.W, z + goff, G.plane, (const kcf *)S.twx, add);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;
