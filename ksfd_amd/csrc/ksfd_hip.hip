@@ -177,8 +177,23 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         for (auto &e : h->gm_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) CFAIL(KSFD_EHIP, "hipEventCreate failed");
     }
 
-    spec_build(h);                                            // leaves spec.ok = false where it does not apply (3-D, slab ranks, non power-of-two extents)
+    spec_build(h);                                            // leaves spec.ok = false where it does not apply (3-D, non power-of-two extents, ...)
     if (mg_build(h)) { mg_free(h); h->mg_ok = false; }        // out of memory for the hierarchy: run without the multigrid preconditioner
+    if (h->spec.ok && alloc_d(h, &h->bstore, 3 * h->vlen)) { h->bstore = nullptr; h->spec_guess = false; h->err.clear(); }
+    if (h->size > 1) {
+        // which solvers exist decides the sequence of collectives of every step: all ranks must agree (an allocation that failed
+        // on one rank only would otherwise leave the others waiting in an all-reduce)
+        double flags[3] = { h->spec.ok ? 1.0 : 0.0, h->mg_ok ? 1.0 : 0.0, (h->spec_guess && h->bstore) ? 1.0 : 0.0 };
+        for (double &f : flags) f = -f;                       // MIN through the transport's MAX
+        if (hipMemcpyAsync(h->dres, flags, sizeof flags, hipMemcpyHostToDevice, h->st) != hipSuccess || h->tr->allreduce(h->dres, 3, 1, h->st))
+            CFAIL(KSFD_ECOMM, "agreeing on the available solvers failed: %s", h->tr->error().c_str());
+        if (h->tr->result_on_host()) memcpy(flags, h->tr->host_result(), sizeof flags);
+        else if (hipMemcpyAsync(flags, h->dres, sizeof flags, hipMemcpyDeviceToHost, h->st) != hipSuccess || hipStreamSynchronize(h->st) != hipSuccess)
+            CFAIL(KSFD_EHIP, "reading the agreed solver flags failed");
+        if (flags[0] > -0.5 && h->spec.ok) spec_free(h);
+        if (flags[1] > -0.5 && h->mg_ok) { mg_free(h); h->mg_ok = false; }
+        if (flags[2] > -0.5) h->spec_guess = false;
+    }
     if (hipStreamSynchronize(h->st) != hipSuccess) CFAIL(KSFD_EHIP, "stream sync failed in create");
 #undef CFAIL
     *out = h;
@@ -649,8 +664,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         // sides of a step are nearly dependent -- b_1 = c b_0 to ~1e-3, later ones to a few per cent (CPU experiment with the oracle)
         // -- so x0 = sum c_j Y_j, c = argmin ||b_i - sum c_j b_j||, starts the defect correction 1-3 digits ahead for one small
         // multi-dot.  The b_j are kept in bstore (three vectors, allocated on first use); gb = their Gram matrix.
-        bool guess_on = use_spec && fuse_stage && h->spec_guess;
-        if (guess_on && !h->bstore && alloc_d(h, &h->bstore, 3 * vs)) { h->bstore = nullptr; guess_on = false; h->err.clear(); }
+        const bool guess_on = use_spec && fuse_stage && h->spec_guess && h->bstore;
         double gb[4][4];
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;

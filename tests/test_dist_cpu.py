@@ -61,6 +61,14 @@ def _worker(rank, size, port, shape, nlig):
         assert red[0] == size * (size + 1) / 2
         mx = np.array([float(rank)])
         assert d.allreduce(None, ptr(mx), 1, 1) == 0 and mx[0] == size - 1
+        # all-to-all (transposes of the slab-distributed spectral solver): block q of `send` -> rank q
+        nb = 24
+        send = np.concatenate([np.full(nb, 16 * rank + q, dtype=np.uint8) for q in range(size)])
+        recv = np.zeros(nb * size, dtype=np.uint8)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert d.alltoall(None, vp(send), vp(recv), nb) == 0
+        for r in range(size):
+            assert np.all(recv[r * nb:(r + 1) * nb] == 16 * r + rank)       # block r came from rank r and was addressed to us
         # --- halo protocol end to end with the oracle as the stencil
         dim = len(shape)
         cfg = ProblemConfig.standard(dim, shape, L=[0.5 + 0.1 * a for a in range(dim)], nlig=nlig)
