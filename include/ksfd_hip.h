@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define KSFD_MAX_LIG 6   /* ligand fields after the reference's fourier_series() expansion */
+#define KSFD_MAX_LIG 12  /* ligand fields after the reference's fourier_series() expansion (KSFD/ksfdligand.py:315-388 has no cap;
+                          * 12 = the dispatch width of the kernels, params.h: KSFD_MAXL) */
 
 enum {
     KSFD_OK = 0,

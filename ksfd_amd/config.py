@@ -9,7 +9,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-MAX_LIG = 7
+MAX_LIG = 12
 
 
 class CConfig(C.Structure):

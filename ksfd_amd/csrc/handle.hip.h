@@ -31,10 +31,14 @@ struct MGLevel {
 // spectral preconditioner (spectral.hip.h / spectral_host.hip.h)
 struct SpecState {
     bool ok = false, means_valid = false, tile_major = false;
-    KFFTPlan px, py;
+    KFFTPlan px, py, pz;
+    int dim = 2, lg_cz = 0, pb = 1, nent = 0, lg_rb3 = 0;          // 3-D: z per block of the y kernels, column pairs per block / entries of the z kernel
+    size_t lds_y3 = 0, lds_z3 = 0;
+    int *posz = nullptr, *kzofpos = nullptr;
+    float *lz = nullptr;
     int rb = 0, npair = 0, nyp = 0;
     size_t lds_rows = 0, lds_cols = 0;
-    kcf *W = nullptr, *W2 = nullptr, *twx = nullptr, *twy = nullptr;     // W: [pair][pos_x][y_local]; W2: after the all-to-all, [rank][pair][own pos][y_local]
+    kcf *W = nullptr, *W2 = nullptr, *twx = nullptr, *twy = nullptr, *twz = nullptr;     // W: [pair][pos_x][y_local]; W2: after the all-to-all, [rank][pair][own pos][y_local]
     int *posy = nullptr, *kyofpos = nullptr;
     int4 *pairtab = nullptr;          // per block of the column kernel
     int nxl = 0, nblk_cols = 0, lg_pl = 0;   // owned positions, column-kernel blocks, log2(rows per rank)

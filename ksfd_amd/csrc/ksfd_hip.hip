@@ -678,8 +678,9 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                     if (h->Ginv[i][j] != 0.0) { cmb.yout[cmb.nout] = h->Y + (int64_t)j * vs; cmb.aout[cmb.nout++] = -h->Ginv[i][j] / hh; }
                 }
                 if (i > 0 && (rc = halo(h, h->Y + (int64_t)(i - 1) * vs))) break;     // ghosts of the newest stage vector (earlier ones done)
-                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, use_spec && !(guess_on && i > 0)))) break;
-                if (use_spec && !(guess_on && i > 0)) bnorm2 = h->hres[0];
+                const bool rhs_norm = use_spec && fused_ok(h) && !(guess_on && i > 0);      // ||b||^2 from the store epilogue (2-D strip kernel)
+                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, rhs_norm))) break;
+                if (rhs_norm) bnorm2 = h->hres[0];
             } else {
             if (i > 0) {
                 const double *xs[5]; double a[5]; int nt = 0;
@@ -704,7 +705,10 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 SpecGuess sg;
                 sg.n = 0;
                 if (guess_on) {
-                    if (i == 0) gb[0][0] = bnorm2;
+                    if (i == 0) {
+                        if (bnorm2 < 0.0) { if ((rc = op_multidot(h, bcur, bcur, 0))) break; bnorm2 = h->hres[0]; }
+                        gb[0][0] = bnorm2;
+                    }
                     else {
                         // <b_i, b_j> (j < i) and <b_i, b_i> in one pass; least squares on the (ill-conditioned but tiny) Gram system
                         if ((rc = op_multidot(h, bcur, h->bstore, i))) break;

@@ -67,7 +67,13 @@ static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
     case 3: { constexpr int NL = 3; CALL; } break;                                                 \
     case 4: { constexpr int NL = 4; CALL; } break;                                                 \
     case 5: { constexpr int NL = 5; CALL; } break;                                                 \
-    default: { constexpr int NL = 6; CALL; } break;                                                \
+    case 6: { constexpr int NL = 6; CALL; } break;                                                 \
+    case 7: { constexpr int NL = 7; CALL; } break;                                                 \
+    case 8: { constexpr int NL = 8; CALL; } break;                                                 \
+    case 9: { constexpr int NL = 9; CALL; } break;                                                 \
+    case 10: { constexpr int NL = 10; CALL; } break;                                               \
+    case 11: { constexpr int NL = 11; CALL; } break;                                               \
+    default: { constexpr int NL = 12; CALL; } break;                                               \
     }
 
 static KStrips make_strips(const ksfd_handle *h, bool jvp = false)

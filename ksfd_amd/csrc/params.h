@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 
-#define KSFD_MAXL 6
+#define KSFD_MAXL 12
 
 // Geometry of the local slab as the kernels see it.
 // Device layout of a vector: F field planes; a plane is (sloc + 2*ng) "slow units" of `inner`

@@ -370,6 +370,47 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
     }
 }
 
+// The symbol stage for one pair of points k, -k: a[p] = c^_p(k), b[p] = c^_p(-k) per field pair in; c^z_p(k), c^z_p(-k) out.
+// L2 = the Laplacian symbol at k (sum over the axes).
+template <int NL>
+__device__ __forceinline__ void kspec_symbol(const KSpecSym &S, float L2, kcf (&a)[(NL + 2) / 2], kcf (&b)[(NL + 2) / 2])
+{
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    kcf vh[2 * npair];
+#pragma unroll
+    for (int p = 0; p < npair; p++) {
+        const kcf bc = kc_conj(b[p]);
+        const kcf su = kc_add(a[p], bc), di = kc_sub(a[p], bc);
+        vh[2 * p] = make_float2(0.5f * su.x, 0.5f * su.y);
+        vh[2 * p + 1] = make_float2(0.5f * di.y, -0.5f * di.x);          // (a - conj b) / (2i)
+    }
+    float den = S.shift - S.a_rr * L2;
+    kcf num = vh[0];
+    float invd[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        const float d = S.shift + S.gam[l] - S.D[l] * L2;
+        invd[l] = __builtin_amdgcn_rcpf(d);
+        const float c = S.a_rU[l] * L2 * invd[l];
+        den -= c * S.s[l];
+        num.x += c * vh[l + 1].x; num.y += c * vh[l + 1].y;
+    }
+    if (!(fabsf(den) >= S.den_floor)) den = den < 0.0f ? -S.den_floor : S.den_floor;
+    const float sc = S.scale * __builtin_amdgcn_rcpf(den);
+    kcf zh[2 * npair];
+    zh[0] = make_float2(num.x * sc, num.y * sc);
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+        zh[l + 1] = make_float2((vh[l + 1].x * S.scale + S.s[l] * zh[0].x) * invd[l], (vh[l + 1].y * S.scale + S.s[l] * zh[0].y) * invd[l]);
+    if (F & 1) zh[F] = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int p = 0; p < npair; p++) {
+        const kcf za = zh[2 * p], zb = zh[2 * p + 1];
+        a[p] = make_float2(za.x - zb.y, za.y + zb.x);                     // c_z(k)  = z_a + i z_b
+        b[p] = make_float2(za.x + zb.y, -za.y + zb.x);                    // c_z(-k) = conj(z_a) + i conj(z_b)
+    }
+}
+
 // one block per {kx, -kx}: forward FFT along y, symbol, inverse FFT along y, in place in W
 // (templated on the ligand count: the per-point arrays of the symbol stage must stay in registers -- with run-time loop
 //  bounds they went to scratch memory and the kernel took 126 us of pure data movement)
@@ -432,43 +473,12 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         const int kym = (ny - ky) & (ny - 1);
         const int m = kspec_pad(mpos), mp = kspec_pad(posy[kym]);
         const float L2 = lx[ca ? kxB : kxA] + ly[ky];
-        kcf vh[2 * npair];
+        kcf a[npair], b[npair];
 #pragma unroll
-        for (int p = 0; p < npair; p++) {
-            const kcf a = kspec_lds[(2 * p + ca) * sstride + m], bc = kc_conj(kspec_lds[(2 * p + cb) * sstride + mp]);
-            const kcf su = kc_add(a, bc), di = kc_sub(a, bc);
-            vh[2 * p] = make_float2(0.5f * su.x, 0.5f * su.y);
-            vh[2 * p + 1] = make_float2(0.5f * di.y, -0.5f * di.x);          // (a - conj b) / (2i)
-        }
-        // arrow-matrix solve with real multipliers
-        float den = S.shift - S.a_rr * L2;
-        kcf num = vh[0];
-        float invd[NL];
+        for (int p = 0; p < npair; p++) { a[p] = kspec_lds[(2 * p + ca) * sstride + m]; b[p] = kspec_lds[(2 * p + cb) * sstride + mp]; }
+        kspec_symbol<NL>(S, L2, a, b);
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
-            const float d = S.shift + S.gam[l] - S.D[l] * L2;
-            invd[l] = __builtin_amdgcn_rcpf(d);
-            const float c = S.a_rU[l] * L2 * invd[l];
-            den -= c * S.s[l];
-            num.x += c * vh[l + 1].x; num.y += c * vh[l + 1].y;
-        }
-        if (!(fabsf(den) >= S.den_floor)) den = den < 0.0f ? -S.den_floor : S.den_floor;
-        const float sc = S.scale * __builtin_amdgcn_rcpf(den);
-        kcf zh[2 * npair];
-        zh[0] = make_float2(num.x * sc, num.y * sc);
-#pragma unroll
-        for (int l = 0; l < NL; l++) {
-            // z_l = (v_l + s_l z_rho)/d_l with the 1/(nx ny) normalisation: z_rho already carries it
-            zh[l + 1] = make_float2((vh[l + 1].x * S.scale + S.s[l] * zh[0].x) * invd[l], (vh[l + 1].y * S.scale + S.s[l] * zh[0].y) * invd[l]);
-        }
-        if (F & 1) zh[F] = make_float2(0.0f, 0.0f);
-#pragma unroll
-        for (int p = 0; p < npair; p++) {
-            const kcf za = zh[2 * p], zb = zh[2 * p + 1];
-            // c_z(k) = z_a + i z_b ;  c_z(-k) = conj(z_a) + i conj(z_b)
-            kspec_lds[(2 * p + ca) * sstride + m] = make_float2(za.x - zb.y, za.y + zb.x);
-            kspec_lds[(2 * p + cb) * sstride + mp] = make_float2(za.x + zb.y, -za.y + zb.x);
-        }
+        for (int p = 0; p < npair; p++) { kspec_lds[(2 * p + ca) * sstride + m] = a[p]; kspec_lds[(2 * p + cb) * sstride + mp] = b[p]; }
     }
     __syncthreads();
     kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
@@ -477,6 +487,117 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         const kcf *q = kspec_lds + s * sstride;
         const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
         *reinterpret_cast<float4 *>(colat(s, y)) = make_float4(c0.x, c0.y, c1.x, c1.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-D (one rank): x rows as above over the nz*ny rows (tile-major store), then
+//   k_spec3_y_fwd : one block per (pos_x, CZ consecutive z): gathers CZ columns over y from the tiles, DIF along y, stores
+//                   W2[pair][pos_x][pos_y][z] (CZ consecutive z per store segment)
+//   k_spec3_z<NL> : PB pairs of columns {(kx,ky), (-kx,-ky)} per block, contiguous in z: DIF, symbol, DIT inverse, in place
+//   k_spec3_y_inv : reads CZ-z segments of W2, DIT inverse along y, stores W3[pair][pos_x][z*ny + y] (contiguous runs of ny)
+// and the inverse x rows over W3.  HBM traffic 48 F N bytes per application (five kernels, four passes over the work arrays).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_spec3_y_fwd(KFFTPlan PY, int nx, int nz, int lg_cz, int npair, int lg_rb, const kcf *__restrict__ Wt,
+                                                      kcf *__restrict__ W2, const kcf *__restrict__ tw)
+{
+    extern __shared__ kcf kspec_lds[];
+    const int ny = PY.n, lg_ny = PY.lg, cz = 1 << lg_cz, jx = blockIdx.y, z0 = blockIdx.x * cz;
+    const int sstride = ny + (ny >> 4) + 1;
+    const int rb = 1 << lg_rb;
+    const long long ntiles = ((long long)ny * nz) >> lg_rb;
+    const int nseq = npair * cz;
+    // sequence s = p*cz + zc ; element y
+    for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
+        const int s = idx >> lg_ny, y = idx & (ny - 1);
+        const int p = s >> lg_cz, zc = s & (cz - 1);
+        const long long R = (long long)(z0 + zc) * ny + y;
+        kspec_lds[s * sstride + kspec_pad(y)] = Wt[(((long long)p * ntiles + (R >> lg_rb)) * nx + jx) * rb + (R & (rb - 1))];
+    }
+    __syncthreads();
+    kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
+    for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
+        const int zc = idx & (cz - 1), rest = idx >> lg_cz;
+        const int jy = rest & (ny - 1), p = rest >> lg_ny;
+        W2[(((long long)p * nx + jx) * ny + jy) * nz + z0 + zc] = kspec_lds[(p * cz + zc) * sstride + kspec_pad(jy)];
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_spec3_y_inv(KFFTPlan PY, int nx, int nz, int lg_cz, int npair, const kcf *__restrict__ W2,
+                                                      kcf *__restrict__ W3, const kcf *__restrict__ tw)
+{
+    extern __shared__ kcf kspec_lds[];
+    const int ny = PY.n, lg_ny = PY.lg, cz = 1 << lg_cz, jx = blockIdx.y, z0 = blockIdx.x * cz;
+    const int sstride = ny + (ny >> 4) + 1;
+    const int nseq = npair * cz;
+    for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
+        const int zc = idx & (cz - 1), rest = idx >> lg_cz;
+        const int jy = rest & (ny - 1), p = rest >> lg_ny;
+        kspec_lds[(p * cz + zc) * sstride + kspec_pad(jy)] = W2[(((long long)p * nx + jx) * ny + jy) * nz + z0 + zc];
+    }
+    __syncthreads();
+    kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
+    const long long nrows = (long long)ny * nz;
+    for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
+        const int s = idx >> lg_ny, y = idx & (ny - 1);
+        const int p = s >> lg_cz, zc = s & (cz - 1);
+        W3[((long long)p * nx + jx) * nrows + (long long)(z0 + zc) * ny + y] = kspec_lds[s * sstride + kspec_pad(y)];
+    }
+}
+
+// pairtab[e] = (column A, column B, kx | ky << 16, self) with column = pos_x * ny + pos_y; self: A == B is its own partner
+template <int NL>
+__global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb, long long ncol, kcf *__restrict__ W2, const kcf *__restrict__ tw,
+                                                  const int4 *__restrict__ pairtab, const int *__restrict__ posz, const int *__restrict__ kzofpos,
+                                                  const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, KSpecSym S)
+{
+    extern __shared__ kcf kspec_lds[];
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int nz = PZ.n;
+    const int sstride = nz + (nz >> 4) + 1;
+    const int e0 = blockIdx.x * pb;
+    const int ne = min(pb, nent - e0);
+    const int nseq = 2 * npair * ne;                              // sequence s = (slot*npair + p)*2 + c
+    const int half = nz >> 1, lg_half = PZ.lg - 1;
+    auto colptr = [&](int s) {
+        const int c = s & 1, p = (s >> 1) % npair, slot = (s >> 1) / npair;
+        const int4 pt = pairtab[e0 + slot];
+        return W2 + ((long long)p * ncol + (c ? pt.y : pt.x)) * nz;
+    };
+    for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
+        const int s = idx >> lg_half, z = 2 * (idx & (half - 1));
+        const float4 t = *reinterpret_cast<const float4 *>(colptr(s) + z);
+        kcf *q = kspec_lds + s * sstride;
+        q[kspec_pad(z)] = make_float2(t.x, t.y);
+        q[kspec_pad(z + 1)] = make_float2(t.z, t.w);
+    }
+    __syncthreads();
+    kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw);
+    for (int item = threadIdx.x; item < ne * nz; item += blockDim.x) {
+        const int slot = item >> PZ.lg, mpos = item & (nz - 1);
+        const int4 pt = pairtab[e0 + slot];
+        const int kz = kzofpos[mpos];
+        const bool self = pt.w != 0;
+        if (self && kz > half) continue;                           // (A, kz) and (A, -kz) are one item
+        const int kzm = (nz - kz) & (nz - 1);
+        const int m = kspec_pad(mpos), mp = kspec_pad(posz[kzm]);
+        const float L2 = lx[pt.z & 0xffff] + ly[pt.z >> 16] + lz[kz];
+        const int sa = slot * npair * 2, cb = self ? 0 : 1;
+        kcf a[npair], b[npair];
+#pragma unroll
+        for (int p = 0; p < npair; p++) { a[p] = kspec_lds[(sa + 2 * p) * sstride + m]; b[p] = kspec_lds[(sa + 2 * p + cb) * sstride + mp]; }
+        kspec_symbol<NL>(S, L2, a, b);
+#pragma unroll
+        for (int p = 0; p < npair; p++) { kspec_lds[(sa + 2 * p) * sstride + m] = a[p]; kspec_lds[(sa + 2 * p + cb) * sstride + mp] = b[p]; }
+    }
+    __syncthreads();
+    kspec_fft_inv(PZ, kspec_lds, sstride, nseq, tw);
+    for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
+        const int s = idx >> lg_half, z = 2 * (idx & (half - 1));
+        if ((s & 1) && pairtab[e0 + (s >> 1) / npair].w) continue;      // the B slot of a self column is a copy
+        const kcf *q = kspec_lds + s * sstride;
+        const kcf c0 = q[kspec_pad(z)], c1 = q[kspec_pad(z + 1)];
+        *reinterpret_cast<float4 *>(colptr(s) + z) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
 

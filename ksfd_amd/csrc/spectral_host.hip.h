@@ -31,7 +31,7 @@ static int spec_pos(const KFFTPlan &P, int k)
 static void spec_free(ksfd_handle *h)
 {
     SpecState &S = h->spec;
-    void *bufs[] = { S.W, S.W2, S.twx, S.twy, S.posy, S.kyofpos, S.pairtab, S.lx, S.ly };
+    void *bufs[] = { S.W, S.W2, S.twx, S.twy, S.twz != S.twy ? S.twz : nullptr, S.posy, S.kyofpos, S.pairtab, S.lx, S.ly, S.posz, S.kzofpos, S.lz };
     for (void *b : bufs) if (b) hipFree(b);
     S = SpecState();
 }
@@ -48,6 +48,93 @@ template <typename T> static bool spec_upload(T **dev, const std::vector<T> &hos
 // the digits handed out in these pairs both columns of every {kx, -kx} pair land on one rank.
 static const int spec_digit_order[16] = { 0, 8, 1, 15, 2, 14, 3, 13, 4, 12, 5, 11, 6, 10, 7, 9 };
 
+static std::vector<kcf> spec_twiddles(int n)
+{
+    std::vector<kcf> t(n);
+    for (int k = 0; k < n; k++) { const double a = -2.0 * M_PI * k / n; t[k] = make_float2((float)cos(a), (float)sin(a)); }
+    return t;
+}
+static std::vector<int> spec_positions(const KFFTPlan &Q) { std::vector<int> p(Q.n); for (int k = 0; k < Q.n; k++) p[k] = spec_pos(Q, k); return p; }
+static std::vector<int> spec_inverse(const std::vector<int> &p) { std::vector<int> q(p.size()); for (size_t k = 0; k < p.size(); k++) q[p[k]] = (int)k; return q; }
+static std::vector<float> spec_symbol_table(int n, double inv_h2)
+{
+    std::vector<float> l(n);
+    for (int k = 0; k < n; k++) { const double th = 2.0 * M_PI * k / n; l[k] = (float)((-30.0 + 32.0 * cos(th) - 2.0 * cos(2.0 * th)) / 12.0 * inv_h2); }
+    return l;
+}
+
+// 3-D, one rank (see spectral.hip.h): plans per axis, the column-pair table of the z kernel, two work arrays
+static void spec_build3d(ksfd_handle *h)
+{
+    SpecState &S = h->spec;
+    const KGeom &G = h->G;
+    if (h->size != 1 || G.ng != 0 || getenv("KSFD_SPEC_NO3D")) return;
+    if (!spec_plan(G.nx, S.px) || !spec_plan(G.ny, S.py) || !spec_plan(G.nz, S.pz)) return;
+    if (S.px.radix[0] != 16 || G.nx > 32768 || G.ny > 32768) return;
+    S.dim = 3;
+    S.npair = (G.F + 1) / 2;
+    const size_t lds_max = 160 * 1024 - 1024;
+    const long long nrows = G.ny * G.nz;
+    const size_t row_bytes = sizeof(kcf) * (size_t)(G.nx + (G.nx >> 4) + 1);
+    int rb = 16;
+    while (rb > 1 && row_bytes * rb > lds_max) rb >>= 1;
+    while (rb > 2 && nrows / rb < 512) rb >>= 1;
+    if (row_bytes * rb > lds_max || nrows % rb || G.ny % rb) return;      // a tile must not straddle two z planes' y ranges unevenly
+    S.rb = rb;
+    S.nyp = (int)nrows;                                            // column stride of the array the inverse row kernel reads
+    S.lg_rb3 = 0; while ((1 << S.lg_rb3) < rb) S.lg_rb3++;
+    S.lds_rows = row_bytes * rb;
+    const size_t ycol = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * S.npair, zcol = sizeof(kcf) * (size_t)(G.nz + (G.nz >> 4) + 1) * 2 * S.npair;
+    int cz = 16;
+    while (cz > 1 && (ycol * cz > lds_max / 2 || G.nz % cz)) cz >>= 1;      // <= half the LDS: two blocks per CU
+    if (ycol * cz > lds_max) return;
+    S.lg_cz = 0; while ((1 << S.lg_cz) < cz) S.lg_cz++;
+    S.lds_y3 = ycol * cz;
+    int pb = 16;
+    while (pb > 1 && zcol * pb > lds_max / 2) pb >>= 1;
+    if (zcol * pb > lds_max) return;
+    S.pb = pb;
+    S.lds_z3 = zcol * pb;
+    {
+        hipError_t e = hipFuncSetAttribute((const void *)k_spec_rows_fwd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_y_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_y3);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_y_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_y3);
+        NL_DISPATCH(h->P.nlig, if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_z<NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3));
+        if (e != hipSuccess) { hipGetLastError(); return; }
+    }
+    // pairs of columns {(kx,ky), (-kx,-ky)}; a column is addressed by its position pair
+    const int nx = (int)G.nx, ny = (int)G.ny;
+    const std::vector<int> posx = spec_positions(S.px), posy = spec_positions(S.py);
+    std::vector<int4> ent;
+    ent.reserve((size_t)nx * ny / 2 + 4);
+    for (int kx = 0; kx <= nx / 2; kx++)
+        for (int ky = 0; ky < ny; ky++) {
+            const int kxm = (nx - kx) % nx, kym = (ny - ky) % ny;
+            const bool self = kxm == kx && kym == ky;
+            if (!self && (kxm < kx || (kxm == kx && kym < ky))) continue;       // the partner comes first: it owns the pair
+            const int ca = posx[kx] * ny + posy[ky], cb = posx[kxm] * ny + posy[kym];
+            ent.push_back(make_int4(ca, cb, kx | (ky << 16), self ? 1 : 0));
+        }
+    std::sort(ent.begin(), ent.end(), [](const int4 &a, const int4 &b) { return a.x < b.x; });
+    S.nent = (int)ent.size();
+    const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nrows;
+    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || hipMalloc((void **)&S.W2, wbytes) != hipSuccess ||
+        !spec_upload(&S.twx, spec_twiddles(S.px.n)) || !spec_upload(&S.twy, spec_twiddles(S.py.n)) ||
+        !spec_upload(&S.posz, spec_positions(S.pz)) || !spec_upload(&S.kzofpos, spec_inverse(spec_positions(S.pz))) || !spec_upload(&S.pairtab, ent) ||
+        !spec_upload(&S.lx, spec_symbol_table(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, spec_symbol_table(S.py.n, h->P.inv_h2[1])) ||
+        !spec_upload(&S.lz, spec_symbol_table(S.pz.n, h->P.inv_h2[2]))) { hipGetLastError(); spec_free(h); return; }
+    // the z transforms need their own twiddle table when nz differs from ny: kept behind twy in one allocation is not worth it
+    if (G.nz != G.ny) {
+        kcf *tz = nullptr;
+        if (!spec_upload(&tz, spec_twiddles(S.pz.n))) { hipGetLastError(); spec_free(h); return; }
+        S.twz = tz;
+    } else S.twz = S.twy;
+    S.tile_major = true;
+    S.ok = true;
+}
+
 // Builds plans, tables and the work arrays if this handle can use the spectral solver; leaves spec.ok = false otherwise.
 static void spec_build(ksfd_handle *h)
 {
@@ -55,6 +142,7 @@ static void spec_build(ksfd_handle *h)
     const KGeom &G = h->G;
     const int P = h->size;
     S.ok = false;
+    if (G.dim == 3) { spec_build3d(h); return; }
     if (G.dim != 2) return;
     if (P > 1 && (!h->tr || !h->tr->has_alltoall() || (P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
     const long long ny = h->cfg.n[1], nyl = G.sloc;                  // global / local rows
@@ -176,10 +264,11 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     memset(&Y, 0, sizeof Y);
     Y.nlig = h->P.nlig;
     Y.shift = (float)shift; Y.a_rr = (float)S.a_rr;
-    Y.scale = (float)(1.0 / ((double)G.nx * (double)h->cfg.n[1]));
+    Y.scale = (float)(1.0 / ((double)G.nx * (double)h->cfg.n[1] * (double)h->cfg.n[2]));
     Y.den_floor = (float)(0.02 * shift);
     for (int l = 0; l < h->P.nlig; l++) { Y.a_rU[l] = (float)S.a_rU[l]; Y.s[l] = (float)h->P.lig_s[l]; Y.gam[l] = (float)h->P.lig_gamma[l]; Y.D[l] = (float)h->P.lig_D[l]; }
-    const int ntiles = (int)(G.sloc / S.rb);
+    const bool d3 = S.dim == 3;
+    const int ntiles = (int)((d3 ? G.ny * G.nz : G.sloc) / S.rb);     // 3-D: the x rows are the nz*ny rows of the box
     const long long goff = (long long)G.ng * G.inner;                // the row kernels address owned rows only
     KSpecLin ex, add;
     memset(&ex, 0, sizeof ex); memset(&add, 0, sizeof add);
@@ -207,6 +296,27 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         if (v32) hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v32 + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx, ex);
         else hipLaunchKernelGGL(k_spec_rows_fwd<double>, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_f, S.nyp, S.rb, S.tile_major ? -ntiles : ntiles, G.F, v + goff, G.plane, S.tile_major ? S.W2 : S.W, (const kcf *)S.twx, ex);
     }
+    if (d3) {
+        const int cz = 1 << S.lg_cz;
+        const int thr_y = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.npair * cz * G.ny / 16));
+        const int thr_z = (int)std::min<long long>(1024, std::max<long long>(256, (long long)2 * S.npair * S.pb * G.nz / 16));
+        {
+            Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
+            hipLaunchKernelGGL(k_spec3_y_fwd, dim3((unsigned)(G.nz / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)G.nz, S.lg_cz, S.npair, S.lg_rb3,
+                               (const kcf *)S.W2, S.W, (const kcf *)S.twy);
+        }
+        {
+            Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec3_z<NL>), dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)G.nx * G.ny, S.W,
+                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y));
+        }
+        {
+            Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
+            hipLaunchKernelGGL(k_spec3_y_inv, dim3((unsigned)(G.nz / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)G.nz, S.lg_cz, S.npair,
+                               (const kcf *)S.W, S.W2, (const kcf *)S.twy);
+        }
+        // the inverse x rows read W3 = S.W2 ([pair][pos_x][z*ny + y]) below
+    } else {
     kcf *Wc = S.W;
     if (h->size > 1) {                                                // rows of everybody's columns -> whole columns of mine
         Scope sc(h, KC_HALO, pn);
@@ -225,9 +335,10 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         Scope sc(h, KC_HALO, pn);
         if (h->tr->alltoall(S.a2a_bwd_s, S.a2a_bwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
     }
+    }
     {
         Scope sc(h, KC_SPECTRAL, pn + 8.0 * (1 + add.n) * fn, 8.0 * (1 + add.n) * fn);     // read W (+ x / guess vectors) | write z
-        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)S.W, z + goff, G.plane, (const kcf *)S.twx, add);
+        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)(d3 ? S.W2 : S.W), z + goff, G.plane, (const kcf *)S.twx, add);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;

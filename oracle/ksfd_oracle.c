@@ -26,7 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define KO_MAXF 8
+#define KO_MAXF 16
 
 /* OpenMP is used only by the cpu_baseline timing leg; default is one thread (tests). */
 static int ko_threads = 1;

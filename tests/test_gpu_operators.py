@@ -220,3 +220,33 @@ def test_device_start_values_vs_reference_random_function(name):
     rho = k.get_state()[:cfg.N].reshape(n, order='F')
     assert np.abs(rho - z['out']).max() <= 1e-13 * np.abs(z['out']).max()
     k.close()
+
+
+def test_nine_ligands_through_the_generic_kernels_vs_oracle():
+    """fourier_series() expansions (KSFD/ksfdligand.py:315-388) can produce more ligand fields than a model names: 9 ligands in
+    3 groups (F = 10) run the generic kernels (the strip kernels are instantiated for <= 4) and must match the oracle; 13 are
+    rejected with KSFD_EINVAL (KSFD_MAX_LIG = 12)"""
+    from oracle import ko
+    nl = 9
+    rng = np.random.default_rng(21)
+    cfg = ProblemConfig(dim=2, n=(24, 20), L=(0.07, 0.06), lig_group=[l % 3 for l in range(nl)], lig_w=0.5 + rng.random(nl),
+                        lig_s=0.005 + 0.01 * rng.random(nl), lig_gamma=0.005 + 0.01 * rng.random(nl), lig_D=1e-6 * (1 + rng.random(nl)),
+                        grp_alpha=[1500.0, 1200.0, 1800.0], grp_beta=[5.56e-4, -3e-4, 2e-4])
+    N = cfg.N
+    rho = 9000 + 900 * rng.standard_normal(N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1 + 0.05 * rng.standard_normal(N)) for l in range(nl)])
+    v = rng.standard_normal(u.size)
+    o = ko.Oracle(cfg)
+    k = klib.KSFDHip(cfg)
+    assert rel_l2(k.rhs(u), o.rhs(u)) < 1e-12
+    assert rel_l2(k.jvp(v, u), o.jvp(u, v)) < 1e-12
+    k.set_state(u)
+    assert rel_l2(k.jvp(v), o.jvp(u, v)) < 1e-12                  # frozen-coefficient path
+    un, err, wr, _ = o.rosw_step(u, 0.05, 0.01, 1e-6, solver='gmres', ksp_rtol=1e-13)
+    t, hn, st, rc = k.step(0.0, 0.05, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-12))
+    assert rel_l2(k.get_state(), un) < 1e-10
+    k.close()
+    with pytest.raises((klib.KSFDError, ValueError)):
+        nl = 13
+        klib.KSFDHip(ProblemConfig(dim=2, n=(16, 16), L=(0.05, 0.05), lig_group=[0] * nl, lig_w=[1.0] * nl, lig_s=[0.01] * nl,
+                                   lig_gamma=[0.01] * nl, lig_D=[1e-6] * nl, grp_alpha=[1500.0], grp_beta=[5.56e-4]))

@@ -150,3 +150,55 @@ def test_automatic_choice_leaves_the_spectral_preconditioner_when_coefficients_v
     if first & klib.PC_SPECTRAL and st.linear_its > 48:
         assert not (st2.pc_used & klib.PC_SPECTRAL)          # it backed off
     k.close()
+
+
+def _numpy_spectral3d(cfg, u, shift, v):
+    nx, ny, nz = cfg.n
+    F, nl = cfg.F, cfg.nlig
+    ug = np.maximum(u.reshape(F, nz, ny, nx), np.array([cfg.rhomin] + [cfg.Umin] * nl)[:, None, None, None])
+    rho = ug[0]
+    ms = cfg.maxscale * cfg.s2
+    th = np.tanh((rho - cfg.rhomax) / cfg.cushion)
+    a_rr = np.mean(rho * (cfg.s2 / rho + ms * (1 - th * th) / cfg.cushion))
+    a_rU = []
+    for l in range(nl):
+        g = cfg.lig_group[l]
+        ssum = cfg.grp_alpha[g] + sum(cfg.lig_w[m] * ug[m + 1] for m in range(nl) if cfg.lig_group[m] == g)
+        a_rU.append(np.mean(rho * (-cfg.grp_beta[g] * cfg.lig_w[l] / ssum)))
+    L2 = (_sym_d2(nx, cfg.L[0] / nx)[None, None, :] + _sym_d2(ny, cfg.L[1] / ny)[None, :, None] + _sym_d2(nz, cfg.L[2] / nz)[:, None, None])
+    vh = np.fft.fftn(v.reshape(F, nz, ny, nx), axes=(1, 2, 3))
+    d = [shift + cfg.lig_gamma[l] - cfg.lig_D[l] * L2 for l in range(nl)]
+    den = shift - a_rr * L2 - sum(a_rU[l] * L2 * cfg.lig_s[l] / d[l] for l in range(nl))
+    z0 = (vh[0] + sum(a_rU[l] * L2 / d[l] * vh[l + 1] for l in range(nl))) / den
+    zs = [z0] + [(vh[l + 1] + cfg.lig_s[l] * z0) / d[l] for l in range(nl)]
+    return np.real(np.fft.ifftn(np.array(zs), axes=(1, 2, 3))).reshape(-1)
+
+
+@pytest.mark.parametrize('shape,nlig', [((32, 32, 32), 1), ((64, 32, 128), 2), ((32, 64, 32), 1)])
+@pytest.mark.parametrize('h', [0.02, 5.0])
+def test_spectral_operator_3d_vs_numpy(shape, nlig, h):
+    cfg = ProblemConfig.standard(3, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=nlig)
+    u = _state(cfg, 3)
+    v = np.random.default_rng(4).standard_normal(u.size)
+    shift = 1.0 / (GAMMA * h)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    got = k.spectral_apply(shift, v)
+    k.close()
+    assert rel_l2(got, _numpy_spectral3d(cfg, u, shift, v)) < 2e-5
+
+
+@pytest.mark.parametrize('pc', [4, 2])
+def test_step_3d_with_spectral_solver_vs_oracle(pc):
+    shape = (32, 32, 32)
+    cfg = ProblemConfig.standard(3, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=1)
+    u = _state(cfg, 9)
+    h = 0.1
+    un, err, wr, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='gmres', ksp_rtol=1e-13, maxit=4000)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-12, pc_type=pc))
+    assert st.pc_used & klib.PC_SPECTRAL
+    assert st.linear_its <= 4 * 18, st.linear_its
+    assert rel_l2(k.get_state(), un) < 1e-10
+    k.close()
