@@ -30,9 +30,10 @@ __device__ __forceinline__ double ksfd_div(double a, double x)
     const double q = a * r;
     return fma(fma(-x, q, a), r, q);                    // one residual correction: correctly rounded but for rare ties
 }
-// log(x), x > 0 normal
+// log(x); the fast path needs 0 < x < inf (what the clamped inputs give), anything else goes to the library
 __device__ __forceinline__ double ksfd_log(double x)
 {
+    if (!(x > 0.0) || x > 1.0e300) return log(x);      // never taken with groomed inputs (a wave-uniform not-taken branch)
     // x = 2^k * m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f/(2+f); log(m) = f - hfsq + s*(hfsq + R(s^2))
     int k = __builtin_amdgcn_frexp_exp(x);              // x = mant * 2^k, mant in [0.5, 1)
     double m = __builtin_amdgcn_frexp_mant(x);
@@ -86,7 +87,7 @@ __device__ __forceinline__ void ksfd_G(const KPhys &P, double rho, const double 
         }
     }
     const double y = (rho - P.rhomax) * P.inv_cushion;
-    const double ay = fabs(y);
+    const double ay = fmin(fabs(y), 300.0);      // exp(-600) is 0 to every use below; keeps the exponent arithmetic in range
     double thp1, sech2;                          // tanh(y) + 1, 1 - tanh(y)^2
     if (ay > 19.5) {                             // exp(-39) < 2^-56: tanh(|y|) rounds to 1 (lanes diverge only at such aggregates)
         thp1 = y > 0.0 ? 2.0 : 2.0 * ksfd_exp(-2.0 * ay);

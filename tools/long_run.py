@@ -1,6 +1,7 @@
 """Production-style run: adaptive integration from dt=1e-8 far into the aggregation phase (options81-style)."""
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 from ksfd_amd import lib as klib
 from ksfd_amd.config import ProblemConfig
@@ -16,6 +17,8 @@ if len(sys.argv) > 4:
 import os
 if os.environ.get('KSFD_TUNE'):
     ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
+if os.environ.get('KSFD_NO_SPECTRAL'):
+    ks.set_spectral_params(enable=0)
 opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
 t, h = 0.0, 1e-8
 T0 = time.perf_counter()
@@ -28,7 +31,7 @@ for s in range(nsteps):
         print('STOP rc', rc, ks.last_error()); break
     if s % 10 == 0 or st.rejections:
         vm = ks.velocity_max()
-        print('step %4d t %.4e h_next %.3e its %4d rej %d wrms %.2e  %.1f ms  vmax %.2e' % (s, t, h, st.linear_its, st.rejections, st.wrms, 1e3 * (time.perf_counter() - t0), vm[0]), flush=True)
+        print('step %4d t %.4e h_next %.3e its %4d rej %d wrms %.2e  %.1f ms  vmax %.2e pc %d' % (s, t, h, st.linear_its, st.rejections, st.wrms, 1e3 * (time.perf_counter() - t0), vm[0], st.pc_used), flush=True)
     if t > 2e5: break
 u = ks.get_state()
 print('done: steps %d t %.4e total its %d wall %.1f s  rho min %.3g max %.3g' % (s + 1, t, tot_its, time.perf_counter() - T0, u[:n*n].min(), u[:n*n].max()))
