@@ -154,8 +154,10 @@ static void hess_lsq(const double *H, int k, const double *g, double *y, double 
 // (d+1) Jacobian actions + Gram-Schmidt).  The iteration then continues on the true residual with the same stopping
 // test, so the result is the same to the solver tolerance.  stage < 0: plain solve from x0 = 0.
 static int gmres(ksfd_handle *h, const double *ustate, double shift, const double *b, double *x,
-                 const ksfd_step_opts *o, LinStats *ls, int pcmode, int stage = -1)
+                 const ksfd_step_opts *o, LinStats *ls, int pcmode, int stage = -1, double tol_abs = -1.0)
 {
+    // tol_abs > 0: stop at that absolute residual norm (the caller solves a correction equation A d = b - A x0 and wants the
+    // tolerance of the original system)
     const bool use_pc = pcmode == 1;       // multigrid, right preconditioning
     // the hierarchy may be built for a LARGER shift than the system's (h->mg_shift_floor): when 1/(gamma h) falls below the growth
     // rate of the chemotactic instability, shift*I - J is indefinite and a V cycle of it is no contraction; the V cycle of the
@@ -202,7 +204,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
         return KSFD_OK;
     }
-    const double tol = std::max(o->ksp_rtol * bn, o->ksp_atol);
+    const double tol = tol_abs > 0.0 ? tol_abs : std::max(o->ksp_rtol * bn, o->ksp_atol);
     double beta = bn, rn = bn;
     int total = 0;
     bool first = true;          // the residual of the current x is at hand (rsrc, norm beta): no A x needed
@@ -403,7 +405,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     }
     if (!x_set) HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
     ls->its = total;
-    ls->rel = rn / bn;
+    ls->rel = rn / ((tol_abs > 0.0 && o->ksp_rtol > 0.0) ? tol_abs / o->ksp_rtol : bn);      // correction equation: relative to the original right-hand side
     if (rn > tol) return fail(h, KSFD_ELINEAR, "GMRES did not converge: %d iterations, relative residual %.3e (tol %.3e)", total, rn / bn, tol / bn);
     return KSFD_OK;
 }

@@ -179,7 +179,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
 
     spec_build(h);                                            // leaves spec.ok = false where it does not apply (3-D, non power-of-two extents, ...)
     if (mg_build(h)) { mg_free(h); h->mg_ok = false; }        // out of memory for the hierarchy: run without the multigrid preconditioner
-    if (h->spec.ok && alloc_d(h, &h->bstore, 3 * h->vlen)) { h->bstore = nullptr; h->spec_guess = false; h->err.clear(); }
+    if ((h->spec.ok || h->mg_ok) && alloc_d(h, &h->bstore, 3 * h->vlen)) { h->bstore = nullptr; h->spec_guess = false; h->err.clear(); }
     if (h->size > 1) {
         // which solvers exist decides the sequence of collectives of every step: all ranks must agree (an allocation that failed
         // on one rank only would otherwise leave the others waiting in an all-reduce)
@@ -664,7 +664,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         // sides of a step are nearly dependent -- b_1 = c b_0 to ~1e-3, later ones to a few per cent (CPU experiment with the oracle)
         // -- so x0 = sum c_j Y_j, c = argmin ||b_i - sum c_j b_j||, starts the defect correction 1-3 digits ahead for one small
         // multi-dot.  The b_j are kept in bstore (three vectors, allocated on first use); gb = their Gram matrix.
-        const bool guess_on = use_spec && fuse_stage && h->spec_guess && h->bstore;
+        const bool guess_on = (use_spec || use_pc) && fuse_stage && h->spec_guess && h->bstore;
         double gb[4][4];
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
@@ -701,9 +701,9 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             }
             LinStats ls;
-            if (use_spec) {
-                SpecGuess sg;
-                sg.n = 0;
+            SpecGuess sg;
+            sg.n = 0;
+            {
                 if (guess_on) {
                     if (i == 0) {
                         if (bnorm2 < 0.0) { if ((rc = op_multidot(h, bcur, bcur, 0))) break; bnorm2 = h->hres[0]; }
@@ -733,6 +733,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                         }
                     }
                 }
+            }
+            if (use_spec) {
                 // defect correction with M^-1 (no Krylov vectors), flexible GMRES for the rest if it contracts slowly; the attempt
                 // is capped so that a state it does not suit costs little, then the V cycle / plain GMRES takes over
                 rc = spec_solve(h, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls, bnorm2, opts->pc_type == 2 ? 40 : 0, sg.n ? &sg : nullptr);
@@ -744,9 +746,20 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                     rc = gmres(h, h->u, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls, mg_here ? 1 : 0);
                     st.pc_used |= mg_here ? 2 : 1;
                 }
+            } else if (use_pc && sg.n) {
+                // multigrid regime, same initial guess: x0 = sum c_j Y_j, TRUE residual r0 = b - A x0 (one Jacobian action), then the
+                // correction A d = r0 to the tolerance of the original system and x = x0 + d
+                double *xi = h->Y + (int64_t)i * vs;
+                const double *xs[3]; double a[3];
+                for (int j = 0; j < sg.n; j++) { xs[j] = sg.Y[j]; a[j] = sg.c[j]; }
+                if ((rc = op_lincomb(h, sg.n, xs, a, xi)) || (rc = halo(h, xi)) || (rc = op_jvp_frozen(h, xi, 2, shift, h->Z, bcur))) break;
+                const double tol = std::max(opts->ksp_rtol * sqrt(bnorm2), opts->ksp_atol);
+                rc = gmres(h, h->u, shift, h->Z, h->t3, opts, &ls, 1, -1, tol);
+                if (!rc) { const double *x2[2] = { xi, h->t3 }; double a2[2] = { 1.0, 1.0 }; rc = op_lincomb(h, 2, x2, a2, xi); }
+                st.pc_used |= 2;
             } else {
-            rc = use_async ? gmres_async(h, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls)
-                           : gmres(h, h->u, shift, h->bvec, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0), i);
+            rc = use_async ? gmres_async(h, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls)
+                           : gmres(h, h->u, shift, bcur, h->Y + (int64_t)i * vs, opts, &ls, use_pc ? 1 : (use_poly ? 2 : 0), i);
             st.pc_used |= use_pc ? 2 : (use_poly ? 4 : 1);
             }
             st.linear_its += ls.its;

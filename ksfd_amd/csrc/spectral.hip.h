@@ -117,32 +117,35 @@ template <int R, bool INV> __device__ __forceinline__ void kc_dft(kcf (&x)[R])
 
 // One in-place stage over `nseq` sequences of length n held in LDS (padded index, `sstride` elements apart).
 // Forward (DIF): y_q = w_L^(i q) * DFT_R(x)_q ; inverse (DIT): x = IDFT_R( conj(w_L^(i q)) y_q ).  tw[k] = exp(-2 pi i k / n).
-template <int R, bool INV>
-__device__ __forceinline__ void kspec_stage(kcf *lds, int sstride, int nseq, int lg_n, int lg_L, const kcf *__restrict__ tw)
+// LG_S = log2 of the element stride S inside a butterfly, compile-time: the padded positions of the R elements are then
+// pad(e0) + CONSTANTS -- pad(e0 + q S) = pad(e0) + q S + (q S >> 4) in every case that occurs (S >= 16: whole runs of 16 are
+// skipped; S < 16 <= R S: e0 = 16-aligned + i with i < S, no carry out of i; R S <= 16: the butterfly lies inside one run) --
+// so the LDS instructions carry immediate offsets and one address is computed per butterfly instead of one per element
+// (measured: the index arithmetic was ~40 % of the VALU instructions of a stage, and the column kernel is VALU-bound).
+template <int R, bool INV, int LG_S>
+__device__ __forceinline__ void kspec_stage(kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw)
 {
     constexpr int lgR = R == 16 ? 4 : (R == 8 ? 3 : (R == 4 ? 2 : 1));
+    constexpr int lg_L = LG_S + lgR, S = 1 << LG_S;
     const int lg_per = lg_n - lgR;          // butterflies per sequence
-    const int lg_S = lg_L - lgR;            // element stride inside a butterfly
-    const int S = 1 << lg_S;
     const int total = nseq << lg_per;
     for (int item = threadIdx.x; item < total; item += blockDim.x) {
         const int s = item >> lg_per, t = item & ((1 << lg_per) - 1);
-        const int g = t >> lg_S, i = t & (S - 1);
-        kcf *base = lds + (long long)s * sstride;
-        const int e0 = (g << lg_L) + i;
+        const int g = t >> LG_S, i = t & (S - 1);
+        kcf *b0 = lds + (long long)s * sstride + kspec_pad((g << lg_L) + i);
         kcf x[R];
 #pragma unroll
-        for (int q = 0; q < R; q++) x[q] = base[kspec_pad(e0 + (q << lg_S))];
+        for (int q = 0; q < R; q++) x[q] = b0[q * S + ((q * S) >> 4)];
         if (!INV) {
             kc_dft<R, false>(x);
-            if (lg_S > 0) {
+            if (LG_S > 0) {
                 const kcf w1 = tw[i << (lg_n - lg_L)];
                 kcf w = w1;
 #pragma unroll
                 for (int q = 1; q < R; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
             }
         } else {
-            if (lg_S > 0) {
+            if (LG_S > 0) {
                 const kcf w1 = kc_conj(tw[i << (lg_n - lg_L)]);
                 kcf w = w1;
 #pragma unroll
@@ -151,7 +154,7 @@ __device__ __forceinline__ void kspec_stage(kcf *lds, int sstride, int nseq, int
             kc_dft<R, true>(x);
         }
 #pragma unroll
-        for (int q = 0; q < R; q++) base[kspec_pad(e0 + (q << lg_S))] = x[q];
+        for (int q = 0; q < R; q++) b0[q * S + ((q * S) >> 4)] = x[q];
     }
 }
 
@@ -205,15 +208,28 @@ __device__ __forceinline__ void kspec_stage0_inv_to(const kcf *lds, int sstride,
     }
 }
 
+// plans are radix 16 from the top with one smaller last stage (spec_plan), so a radix below 16 only ever runs at S = 1
 template <bool INV>
 __device__ __forceinline__ void kspec_stage_any(int radix, kcf *lds, int sstride, int nseq, int lg_n, int lg_L, const kcf *__restrict__ tw)
 {
-    switch (radix) {
-    case 16: kspec_stage<16, INV>(lds, sstride, nseq, lg_n, lg_L, tw); break;
-    case 8: kspec_stage<8, INV>(lds, sstride, nseq, lg_n, lg_L, tw); break;
-    case 4: kspec_stage<4, INV>(lds, sstride, nseq, lg_n, lg_L, tw); break;
-    default: kspec_stage<2, INV>(lds, sstride, nseq, lg_n, lg_L, tw); break;
+    if (radix == 16) {
+        switch (lg_L - 4) {
+        case 0: kspec_stage<16, INV, 0>(lds, sstride, nseq, lg_n, tw); break;
+        case 1: kspec_stage<16, INV, 1>(lds, sstride, nseq, lg_n, tw); break;
+        case 2: kspec_stage<16, INV, 2>(lds, sstride, nseq, lg_n, tw); break;
+        case 3: kspec_stage<16, INV, 3>(lds, sstride, nseq, lg_n, tw); break;
+        case 4: kspec_stage<16, INV, 4>(lds, sstride, nseq, lg_n, tw); break;
+        case 5: kspec_stage<16, INV, 5>(lds, sstride, nseq, lg_n, tw); break;
+        case 6: kspec_stage<16, INV, 6>(lds, sstride, nseq, lg_n, tw); break;
+        case 7: kspec_stage<16, INV, 7>(lds, sstride, nseq, lg_n, tw); break;
+        case 8: kspec_stage<16, INV, 8>(lds, sstride, nseq, lg_n, tw); break;
+        case 9: kspec_stage<16, INV, 9>(lds, sstride, nseq, lg_n, tw); break;
+        default: kspec_stage<16, INV, 10>(lds, sstride, nseq, lg_n, tw); break;      // n = 16384, the largest spec_plan accepts
+        }
     }
+    else if (radix == 8) kspec_stage<8, INV, 0>(lds, sstride, nseq, lg_n, tw);
+    else if (radix == 4) kspec_stage<4, INV, 0>(lds, sstride, nseq, lg_n, tw);
+    else kspec_stage<2, INV, 0>(lds, sstride, nseq, lg_n, tw);
 }
 __device__ __forceinline__ int kspec_lg(int r) { return r == 16 ? 4 : (r == 8 ? 3 : (r == 4 ? 2 : 1)); }
 

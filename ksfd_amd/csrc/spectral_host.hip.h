@@ -9,7 +9,7 @@ static bool spec_plan(long long n, KFFTPlan &P)
     while ((1LL << lg) < n) lg++;
     P.n = (int)n; P.lg = lg; P.nstage = 0;
     int left = lg;
-    static const int lgmax = getenv("KSFD_SPEC_RADIX") ? (atoi(getenv("KSFD_SPEC_RADIX")) == 4 ? 2 : (atoi(getenv("KSFD_SPEC_RADIX")) == 8 ? 3 : 4)) : 4;   // experiment knob
+    const int lgmax = 4;         // radix 16 from the top, one smaller last stage (kspec_stage_any relies on exactly this shape)
     while (left >= lgmax && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << lgmax; left -= lgmax; }
     if (left && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << left; left = 0; }
     return left == 0;
