@@ -34,6 +34,7 @@ typedef float2 kcf;
 struct KFFTPlan {
     int n, lg, nstage;
     int radix[KSPEC_MAXSTAGE];     // DIF stage order; prod = n
+    int flags;                     // kernel variants (spec_apply): bit0/bit1 = first/last stage of k_spec_cols fused with its loads/stores, bit2 = first stage of k_spec_rows_fwd<float>
 };
 
 // a few fp64 vectors with coefficients: added to the input of the forward row kernel / to the output of the inverse one
@@ -163,49 +164,65 @@ __device__ __forceinline__ void kspec_stage(kcf *lds, int sstride, int nseq, int
 //            16 loads of a thread are all in flight at once; outputs go to the LDS for the remaining stages
 //   inverse: the last stage of the DIT inverse hands its 16 outputs to st(sequence, element, value)
 // Consecutive lanes own consecutive elements, so every load/store instruction of a wave is one contiguous run.
-template <typename LD>
-__device__ __forceinline__ void kspec_stage0_fwd_from(kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw, LD ld)
+template <int LG_S, typename LD>
+__device__ __forceinline__ void kspec_stage0_fwd_from_t(kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw, LD ld)
 {
-    const int lg_S = lg_n - 4, S = 1 << lg_S;
-    const int total = nseq << lg_S;
+    constexpr int S = 1 << LG_S;
+    const int total = nseq << LG_S;
     for (int item = threadIdx.x; item < total; item += blockDim.x) {
-        const int s = item >> lg_S, i = item & (S - 1);
+        const int s = item >> LG_S, i = item & (S - 1);
         kcf x[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) x[q] = ld(s, i + (q << lg_S));
+        for (int q = 0; q < 16; q++) x[q] = ld(s, i, q);              // element i + q S
         kc_dft<16, false>(x);
-        if (lg_S > 0) {
+        if (LG_S > 0) {
             const kcf w1 = tw[i];
             kcf w = w1;
 #pragma unroll
             for (int q = 1; q < 16; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
         }
-        kcf *base = lds + (long long)s * sstride;
+        kcf *b0 = lds + (long long)s * sstride + kspec_pad(i);
 #pragma unroll
-        for (int q = 0; q < 16; q++) base[kspec_pad(i + (q << lg_S))] = x[q];
+        for (int q = 0; q < 16; q++) b0[q * S + ((q * S) >> 4)] = x[q];
     }
 }
-template <typename ST>
-__device__ __forceinline__ void kspec_stage0_inv_to(const kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw, ST st)
+template <int LG_S, typename ST>
+__device__ __forceinline__ void kspec_stage0_inv_to_t(const kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw, ST st)
 {
-    const int lg_S = lg_n - 4, S = 1 << lg_S;
-    const int total = nseq << lg_S;
+    constexpr int S = 1 << LG_S;
+    const int total = nseq << LG_S;
     for (int item = threadIdx.x; item < total; item += blockDim.x) {
-        const int s = item >> lg_S, i = item & (S - 1);
-        const kcf *base = lds + (long long)s * sstride;
+        const int s = item >> LG_S, i = item & (S - 1);
+        const kcf *b0 = lds + (long long)s * sstride + kspec_pad(i);
         kcf x[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) x[q] = base[kspec_pad(i + (q << lg_S))];
-        if (lg_S > 0) {
+        for (int q = 0; q < 16; q++) x[q] = b0[q * S + ((q * S) >> 4)];
+        if (LG_S > 0) {
             const kcf w1 = kc_conj(tw[i]);
             kcf w = w1;
 #pragma unroll
             for (int q = 1; q < 16; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
         }
         kc_dft<16, true>(x);
-#pragma unroll
-        for (int q = 0; q < 16; q++) st(s, i + (q << lg_S), x[q]);
+        st(s, i, x);                                   // the 16 outputs: elements i + q S, q = 0..15
     }
+}
+// run-time stride -> the compile-time instance (n = 32 ... 16384)
+#define KSPEC_LGS_DISPATCH(lgs, CALL) \
+    switch (lgs) { \
+    case 1: { constexpr int LGS = 1; CALL; } break; case 2: { constexpr int LGS = 2; CALL; } break; case 3: { constexpr int LGS = 3; CALL; } break; \
+    case 4: { constexpr int LGS = 4; CALL; } break; case 5: { constexpr int LGS = 5; CALL; } break; case 6: { constexpr int LGS = 6; CALL; } break; \
+    case 7: { constexpr int LGS = 7; CALL; } break; case 8: { constexpr int LGS = 8; CALL; } break; case 9: { constexpr int LGS = 9; CALL; } break; \
+    default: { constexpr int LGS = 10; CALL; } break; }
+template <typename LD>
+__device__ __forceinline__ void kspec_stage0_fwd_from(kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw, LD ld)
+{
+    KSPEC_LGS_DISPATCH(lg_n - 4, (kspec_stage0_fwd_from_t<LGS>(lds, sstride, nseq, tw, ld)));
+}
+template <typename ST>
+__device__ __forceinline__ void kspec_stage0_inv_to(const kcf *lds, int sstride, int nseq, int lg_n, const kcf *__restrict__ tw, ST st)
+{
+    KSPEC_LGS_DISPATCH(lg_n - 4, (kspec_stage0_inv_to_t<LGS>(lds, sstride, nseq, tw, st)));
 }
 
 // plans are radix 16 from the top with one smaller last stage (spec_plan), so a radix below 16 only ever runs at S = 1
@@ -279,8 +296,19 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
     const int half = nx >> 1, lg_half = PX.lg - 1;
     const int lg_rb = 31 - __clz(rb);             // rb is a power of two (spec_build)
     // loads in batches of 4 items per thread, all issued before the first LDS store (one memory latency per batch, not per item).
-    // (Measured and dropped: feeding the first radix-16 stage straight from global memory -- 128 VGPRs + spills at 1024 threads,
-    //  151 -> 187 us; the same fusion on the store side of the inverse kernel is kept, it has the registers to spare.)
+    // fp32 input (the residual of the defect correction): first stage straight from global memory, 16 x 2 scalar loads in flight
+    // per thread (85 -> 76 us in the solver; with fp64 input the same fusion is SLOWER, 118 -> 136 us, and stays off)
+    if (sizeof(TIN) == 4 && PX.nstage > 0 && PX.radix[0] == 16 && ex.n == 0 && (PX.flags & 4)) {
+        const int S0 = nx >> 4;
+        kspec_stage0_fwd_from(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int i, int q) {
+            const TIN *pa = va + (long long)r * nx + i, *pb = vb + (long long)r * nx + i;
+            const TIN a = pa[q * S0];
+            const TIN b = has_b ? pb[q * S0] : (TIN)0;
+            return make_float2((float)a, (float)b);
+        });
+        __syncthreads();
+        kspec_fft_fwd(PX, kspec_lds, sstride, rb, tw, 1);
+    } else {
     for (int base = 0; base < rb * half; base += 4 * blockDim.x) {
         double2 a[4], b[4];
 #pragma unroll
@@ -312,6 +340,7 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
     }
     __syncthreads();
     kspec_fft_fwd(PX, kspec_lds, sstride, rb, tw);
+    }
     if (ntiles < 0) {
         // one rank: TILE-MAJOR store Wt[pair][tile][pos][r] -- one contiguous run per block (the transposed store below writes
         // 32-B segments, 151 -> 95 us); the column kernel gathers its columns from the tiles instead (strided READS are cheap: the
@@ -359,12 +388,29 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
     const long long o0 = (long long)(2 * p) * plane + (long long)y0 * nx;
     if (PX.nstage > 0 && PX.radix[0] == 16) {
         kspec_fft_inv(PX, kspec_lds, sstride, rb, tw, 1);
-        kspec_stage0_inv_to(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int e, kcf c) {
-            const long long o = o0 + (long long)r * nx + e;
-            double a = (double)c.x, b = (double)c.y;
-            for (int j = 0; j < add.n; j++) { a += add.a[j] * add.p[j][o]; if (has_b) b += add.a[j] * add.p[j][o + plane]; }
-            z[o] = a;
-            if (has_b) z[o + plane] = b;
+        const int S0 = nx >> 4;
+        kspec_stage0_inv_to(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int i, kcf (&c)[16]) {
+            const long long o = o0 + (long long)r * nx + i;
+            // the vectors added to the result (the iterate x of the defect correction) in batches of 8 elements, ALL loads of a
+            // batch issued before its first store: z may alias them, so left to itself the compiler keeps load-store order and
+            // every thread has two loads in flight (197 us with the x update against 100 us without, 4096^2)
+#pragma unroll
+            for (int hb = 0; hb < 16; hb += 8) {
+                double a[8], b[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { a[q] = (double)c[hb + q].x; b[q] = (double)c[hb + q].y; }
+#pragma unroll
+                for (int j = 0; j < 3; j++)         // (constant trip count: a run-time bound put the by-value struct into scratch memory)
+                    if (j < add.n) {
+                        double ta[8], tb[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { ta[q] = add.p[j][o + (hb + q) * S0]; tb[q] = has_b ? add.p[j][o + (hb + q) * S0 + plane] : 0.0; }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { a[q] += add.a[j] * ta[q]; b[q] += add.a[j] * tb[q]; }
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; q++) { z[o + (hb + q) * S0] = a[q]; if (has_b) z[o + (hb + q) * S0 + plane] = b[q]; }
+            }
         });
         return;
     }
@@ -453,7 +499,19 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     auto colat = [&](int s, int y) {                           // y even: a float4 never straddles two pieces
         return W + (long long)(y >> lg_pl) * pstride + (((long long)(s >> 1) * nxl + ((s & 1) ? jB : jA)) << lg_pl) + (y & plmask);
     };
-    // (first/last stage fused with the global loads/stores was measured here too: 154 VGPRs -> one block per CU, 134 -> 157 us)
+    const bool r16 = PY.nstage > 0 && PY.radix[0] == 16 && (lg_rb < 0 || (ny >> 4) >= (1 << lg_rb));      // (a tile never holds two butterfly elements)
+    if (r16 && (PY.flags & 1)) {
+        // element y = i + q S0 (S0 = ny/16 >= 2^lg_rb and >= 2^lg_pl pieces are whole multiples): q moves by a constant stride
+        const int S0 = ny >> 4;
+        const long long qs = lg_rb >= 0 ? (long long)S0 * nxl : (lg_pl >= PY.lg ? (long long)S0 : 0);
+        kspec_stage0_fwd_from(kspec_lds, sstride, nseq, PY.lg, tw, [&](int s, int i, int q) {
+            const kcf *p0 = lg_rb >= 0 ? Wt + ((((long long)(s >> 1) * (ny >> lg_rb) + (i >> lg_rb)) * nxl + ((s & 1) ? jB : jA)) << lg_rb) + (i & ((1 << lg_rb) - 1))
+                                       : colat(s, i);
+            return qs ? p0[q * qs] : *colat(s, i + q * S0);
+        });
+        __syncthreads();
+        kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw, 1);
+    } else {
     for (int base = 0; base < nseq * half; base += 8 * blockDim.x) {
         float4 t[8];
 #pragma unroll
@@ -478,6 +536,7 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     }
     __syncthreads();
     kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
+    }
     // symbol stage.  item -> the pair of points k = (colA', ky), -k = (colB', -ky), walked in POSITION order of ky so that
     // both LDS accesses of a wave are consecutive (the partner positions of consecutive positions run consecutively backwards)
     const int nitem = self ? 2 * ny : ny;
@@ -497,6 +556,16 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         for (int p = 0; p < npair; p++) { kspec_lds[(2 * p + ca) * sstride + m] = a[p]; kspec_lds[(2 * p + cb) * sstride + mp] = b[p]; }
     }
     __syncthreads();
+    if (r16 && (PY.flags & 2)) {
+        kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw, 1);
+        const int S0 = ny >> 4;
+        const bool whole = lg_pl >= PY.lg;                       // one piece per column (one rank)
+        kspec_stage0_inv_to(kspec_lds, sstride, nseq, PY.lg, tw, [&](int s, int i, kcf (&c)[16]) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) { if (whole) colat(s, i)[q * S0] = c[q]; else *colat(s, i + q * S0) = c[q]; }
+        });
+        return;
+    }
     kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
         const int s = idx >> lg_half, y = 2 * (idx & (half - 1));

@@ -7,7 +7,7 @@ static bool spec_plan(long long n, KFFTPlan &P)
     if (n < 32 || n > 16384 || (n & (n - 1))) return false;
     int lg = 0;
     while ((1LL << lg) < n) lg++;
-    P.n = (int)n; P.lg = lg; P.nstage = 0;
+    P.n = (int)n; P.lg = lg; P.nstage = 0; P.flags = 0;
     int left = lg;
     const int lgmax = 4;         // radix 16 from the top, one smaller last stage (kspec_stage_any relies on exactly this shape)
     while (left >= lgmax && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << lgmax; left -= lgmax; }
@@ -286,6 +286,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     if (diag & 1) px_f.nstage = 0;
     if (diag & 2) py_c.nstage = 0;
     if (diag & 4) px_i.nstage = 0;
+    static const int fuse = getenv("KSFD_SPEC_FUSE") ? atoi(getenv("KSFD_SPEC_FUSE")) : 7;
+    px_f.flags = py_c.flags = px_i.flags = fuse;
     int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
     if (getenv("KSFD_SPEC_THRR")) thr_rows = atoi(getenv("KSFD_SPEC_THRR"));
     int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * S.npair * ny_glob / 16));
