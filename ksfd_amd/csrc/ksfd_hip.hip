@@ -443,6 +443,15 @@ static int velocity_common(ksfd_handle *h, const double *uin, double *vel_dev, d
         nb = bx * by;
         Scope sc(h, KC_VELOCITY, 8.0 * (double)G.nloc);
         hipLaunchKernelGGL(k_velmax2d, dim3(bx, by), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Gplane, h->part);
+    } else if (vmax && !vel_dev && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && G.ny >= 4 && G.nx * G.ny < (1LL << 30)) {
+        const int bx = (int)((G.nx / 2 * G.ny + KSFD_BLOCK - 1) / KSFD_BLOCK);
+        int zseg = (int)G.sloc;                               // enough blocks to fill the chip, segments of >= 8 planes (4 extra loads each)
+        while (zseg >= 32 && (long long)bx * ((G.sloc + zseg - 1) / zseg) < 8192) zseg = (zseg + 1) / 2;
+        const int by = (int)((G.sloc + zseg - 1) / zseg);
+        nb = bx * by;
+        if (3LL * nb > part_capacity()) return fail(h, KSFD_EINVAL, "velocity_max: grid too large for the partial-result buffer");
+        Scope sc(h, KC_VELOCITY, 8.0 * (double)G.nloc);
+        hipLaunchKernelGGL(k_velmax3d, dim3(bx, by), dim3(KSFD_BLOCK), 0, h->st, G, h->P, zseg, Gplane, h->part);
     } else {
         Scope sc(h, KC_VELOCITY, 8.0 * (double)G.nloc * (1 + (vel_dev ? G.dim : 0)));
         hipLaunchKernelGGL(k_velocity, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, G, h->P, Gplane, vel_dev, vmax ? h->part : (double *)nullptr);
