@@ -273,6 +273,33 @@ def test_krylov_recycling_across_stages_saves_iterations_same_answer():
     k.close()
 
 
+def test_stage_guesses_in_the_multigrid_regime_save_iterations_same_answer():
+    """x0 = least-squares combination of the earlier stage solutions of the step (ksfd_step, multigrid branch): the correction
+    equation is solved to the tolerance of the ORIGINAL system on the true residual b - A x0, so the step equals the oracle's
+    LU step with the guesses on and off; with them the V-cycle iteration count of stages 2-4 drops"""
+    cfg = ProblemConfig.standard(2, (32, 32), L=(0.08, 0.08), nlig=2)
+    rng = np.random.default_rng(11)
+    N = 32 * 32
+    rho = 9000 + 90 * rng.standard_normal(N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(2)])
+    h = 20.0
+    un, _, _, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='lu')
+    k = klib.KSFDHip(cfg)
+    res = {}
+    for name, tune in (('on', 1), ('off', 1 | 16384)):
+        k.set_tuning(use_fused=tune)
+        for tol in (1e-6, 1e-11):
+            k.set_state(u)
+            t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=tol, pc_type=1))
+            assert st.pc_used & 2
+            res[name, tol] = (st.linear_its, k.get_state())
+    assert res['on', 1e-6][0] < res['off', 1e-6][0], (res['on', 1e-6][0], res['off', 1e-6][0])
+    for name in ('on', 'off'):
+        assert rel_l2(res[name, 1e-11][1], un) < 1e-9, name
+        assert rel_l2(res[name, 1e-6][1], un) < 1e-6, name
+    k.close()
+
+
 @pytest.mark.parametrize('restart', [5, 9])
 def test_short_restart_lengths_give_the_same_step(restart):
     """large grids run with a restart length sized to the free HBM (ksfd_create); restarts + recycling with few slots must
