@@ -481,13 +481,46 @@ __device__ __forceinline__ void kspec_symbol(const KSpecSym &S, float L2, kcf (&
 // (jlA, jlB, kxA, self): the two local positions the block owns, the wavenumber of the first, and whether both are self-paired.
 // lg_rb >= 0 (one rank): the columns are READ from the tile-major array Wt[pair][tile][pos][r] the row kernel wrote
 // (r = y mod 2^lg_rb) and written to W[pair][pos][y] for the inverse row kernel; lg_rb < 0: in place in W.
+// the symbol stage of k_spec_cols for NL ligands.  item -> the pair of points k = (colA', ky), -k = (colB', -ky), walked in POSITION
+// order of ky so that both LDS accesses of a wave are consecutive (the partner positions of consecutive positions run backwards)
 template <int NL>
+__device__ __forceinline__ void kspec_cols_symbol(const KFFTPlan &PY, kcf *lds, int sstride, bool self, int kxA, int kxB, const int *__restrict__ posy,
+                                                  const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly, const KSpecSym &S)
+{
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int ny = PY.n, half = ny >> 1;
+    const int nitem = self ? 2 * ny : ny;
+    for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
+        const int mpos = item & (ny - 1);
+        const int ky = kyofpos[mpos];
+        int ca = 0, cb = 1;
+        if (self) { ca = cb = item >> PY.lg; if (ky > half) continue; }      // (c, ky) and (c, -ky) are one item
+        const int kym = (ny - ky) & (ny - 1);
+        const int m = kspec_pad(mpos), mp = kspec_pad(posy[kym]);
+        const float L2 = lx[ca ? kxB : kxA] + ly[ky];
+        kcf a[npair], b[npair];
+#pragma unroll
+        for (int p = 0; p < npair; p++) { a[p] = lds[(2 * p + ca) * sstride + m]; b[p] = lds[(2 * p + cb) * sstride + mp]; }
+        kspec_symbol<NL>(S, L2, a, b);
+#pragma unroll
+        for (int p = 0; p < npair; p++) { lds[(2 * p + ca) * sstride + m] = a[p]; lds[(2 * p + cb) * sstride + mp] = b[p]; }
+    }
+}
+// compile-time ligand count for the per-point register arrays of the symbol stage, chosen INSIDE the kernel: the transforms around it
+// do not depend on it, and one instance of them per kernel instead of twelve is what keeps the build at a minute
+#define KSPEC_NL_SWITCH(nl, CALL) \
+    switch (nl) { \
+    case 1: { constexpr int NL = 1; CALL; } break; case 2: { constexpr int NL = 2; CALL; } break; case 3: { constexpr int NL = 3; CALL; } break; \
+    case 4: { constexpr int NL = 4; CALL; } break; case 5: { constexpr int NL = 5; CALL; } break; case 6: { constexpr int NL = 6; CALL; } break; \
+    case 7: { constexpr int NL = 7; CALL; } break; case 8: { constexpr int NL = 8; CALL; } break; case 9: { constexpr int NL = 9; CALL; } break; \
+    case 10: { constexpr int NL = 10; CALL; } break; case 11: { constexpr int NL = 11; CALL; } break; default: { constexpr int NL = 12; CALL; } break; }
+
 __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ Wt, int lg_rb, const kcf *__restrict__ tw,
                                                    const int4 *__restrict__ pairtab, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
-    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int npair = (S.nlig + 2) / 2;
     const int ny = PY.n;
     const int4 pt = pairtab[kspec_tile(blockIdx.x, gridDim.x)];       // consecutive pairs (= neighbouring positions) on one XCD
     const bool self = pt.w != 0;                                // kx = 0 and kx = nx/2 are their own partners
@@ -537,24 +570,7 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     __syncthreads();
     kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
     }
-    // symbol stage.  item -> the pair of points k = (colA', ky), -k = (colB', -ky), walked in POSITION order of ky so that
-    // both LDS accesses of a wave are consecutive (the partner positions of consecutive positions run consecutively backwards)
-    const int nitem = self ? 2 * ny : ny;
-    for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
-        const int mpos = item & (ny - 1);
-        const int ky = kyofpos[mpos];
-        int ca = 0, cb = 1;
-        if (self) { ca = cb = item >> PY.lg; if (ky > half) continue; }      // (c, ky) and (c, -ky) are one item
-        const int kym = (ny - ky) & (ny - 1);
-        const int m = kspec_pad(mpos), mp = kspec_pad(posy[kym]);
-        const float L2 = lx[ca ? kxB : kxA] + ly[ky];
-        kcf a[npair], b[npair];
-#pragma unroll
-        for (int p = 0; p < npair; p++) { a[p] = kspec_lds[(2 * p + ca) * sstride + m]; b[p] = kspec_lds[(2 * p + cb) * sstride + mp]; }
-        kspec_symbol<NL>(S, L2, a, b);
-#pragma unroll
-        for (int p = 0; p < npair; p++) { kspec_lds[(2 * p + ca) * sstride + m] = a[p]; kspec_lds[(2 * p + cb) * sstride + mp] = b[p]; }
-    }
+    KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol<NL>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S)));
     __syncthreads();
     if (r16 && (PY.flags & 2)) {
         kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw, 1);
@@ -630,14 +646,38 @@ __global__ void __launch_bounds__(1024) k_spec3_y_inv(KFFTPlan PY, int nx, int n
     }
 }
 
-// pairtab[e] = (column A, column B, kx | ky << 16, self) with column = pos_x * ny + pos_y; self: A == B is its own partner
 template <int NL>
+__device__ __forceinline__ void kspec3_z_symbol(const KFFTPlan &PZ, kcf *kspec_lds, int sstride, int ne, int e0, const int4 *__restrict__ pairtab, const int *__restrict__ posz,
+                                                const int *__restrict__ kzofpos, const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, const KSpecSym &S)
+{
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int nz = PZ.n, half = nz >> 1;
+    for (int item = threadIdx.x; item < ne * nz; item += blockDim.x) {
+        const int slot = item >> PZ.lg, mpos = item & (nz - 1);
+        const int4 pt = pairtab[e0 + slot];
+        const int kz = kzofpos[mpos];
+        const bool self = pt.w != 0;
+        if (self && kz > half) continue;                           // (A, kz) and (A, -kz) are one item
+        const int kzm = (nz - kz) & (nz - 1);
+        const int m = kspec_pad(mpos), mp = kspec_pad(posz[kzm]);
+        const float L2 = lx[pt.z & 0xffff] + ly[pt.z >> 16] + lz[kz];
+        const int sa = slot * npair * 2, cb = self ? 0 : 1;
+        kcf a[npair], b[npair];
+#pragma unroll
+        for (int p = 0; p < npair; p++) { a[p] = kspec_lds[(sa + 2 * p) * sstride + m]; b[p] = kspec_lds[(sa + 2 * p + cb) * sstride + mp]; }
+        kspec_symbol<NL>(S, L2, a, b);
+#pragma unroll
+        for (int p = 0; p < npair; p++) { kspec_lds[(sa + 2 * p) * sstride + m] = a[p]; kspec_lds[(sa + 2 * p + cb) * sstride + mp] = b[p]; }
+    }
+}
+
+// pairtab[e] = (column A, column B, kx | ky << 16, self) with column = pos_x * ny + pos_y; self: A == B is its own partner
 __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb, long long ncol, kcf *__restrict__ W2, const kcf *__restrict__ tw,
                                                   const int4 *__restrict__ pairtab, const int *__restrict__ posz, const int *__restrict__ kzofpos,
                                                   const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
-    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int npair = (S.nlig + 2) / 2;
     const int nz = PZ.n;
     const int sstride = nz + (nz >> 4) + 1;
     const int e0 = blockIdx.x * pb;
@@ -658,23 +698,7 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
     }
     __syncthreads();
     kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw);
-    for (int item = threadIdx.x; item < ne * nz; item += blockDim.x) {
-        const int slot = item >> PZ.lg, mpos = item & (nz - 1);
-        const int4 pt = pairtab[e0 + slot];
-        const int kz = kzofpos[mpos];
-        const bool self = pt.w != 0;
-        if (self && kz > half) continue;                           // (A, kz) and (A, -kz) are one item
-        const int kzm = (nz - kz) & (nz - 1);
-        const int m = kspec_pad(mpos), mp = kspec_pad(posz[kzm]);
-        const float L2 = lx[pt.z & 0xffff] + ly[pt.z >> 16] + lz[kz];
-        const int sa = slot * npair * 2, cb = self ? 0 : 1;
-        kcf a[npair], b[npair];
-#pragma unroll
-        for (int p = 0; p < npair; p++) { a[p] = kspec_lds[(sa + 2 * p) * sstride + m]; b[p] = kspec_lds[(sa + 2 * p + cb) * sstride + mp]; }
-        kspec_symbol<NL>(S, L2, a, b);
-#pragma unroll
-        for (int p = 0; p < npair; p++) { kspec_lds[(sa + 2 * p) * sstride + m] = a[p]; kspec_lds[(sa + 2 * p + cb) * sstride + mp] = b[p]; }
-    }
+    KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S)));
     __syncthreads();
     kspec_fft_inv(PZ, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {

@@ -101,7 +101,7 @@ static void spec_build3d(ksfd_handle *h)
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_y_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_y3);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_y_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_y3);
-        NL_DISPATCH(h->P.nlig, if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_z<NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_z, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
     // pairs of columns {(kx,ky), (-kx,-ky)}; a column is addressed by its position pair
@@ -166,7 +166,7 @@ static void spec_build(ksfd_handle *h)
         hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess) { hipGetLastError(); return; }
     {
         hipError_t e = hipSuccess;
-        NL_DISPATCH(h->P.nlig, e = hipFuncSetAttribute((const void *)k_spec_cols<NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols));
+        e = hipFuncSetAttribute((const void *)k_spec_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
     auto twiddles = [](int n) {
@@ -309,8 +309,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         }
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec3_z<NL>), dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)G.nx * G.ny, S.W,
-                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y));
+            hipLaunchKernelGGL(k_spec3_z, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)G.nx * G.ny, S.W,
+                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y);
         }
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
@@ -330,8 +330,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         const long long pstride = (long long)S.npair * S.nxl << S.lg_pl;
         int lg_rb = 0;
         while ((1 << lg_rb) < S.rb) lg_rb++;
-        NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_spec_cols<NL>), dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy,
-                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y));
+        hipLaunchKernelGGL(k_spec_cols, dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy,
+                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
     }
     if (h->size > 1) {
         Scope sc(h, KC_HALO, pn);
