@@ -75,17 +75,26 @@ def _three_ligands(shape, L):
                          grp_beta=[5.56e-4, -5.56e-4])
 
 
+def _many_ligands(dim, shape, L, nl):
+    """nl ligands in three groups (fourier_series()-style expansions): exercises the larger symbol blocks"""
+    rng = np.random.default_rng(100 + nl)
+    return ProblemConfig(dim=dim, n=shape, L=L, lig_group=[l % 3 for l in range(nl)], lig_w=0.5 + rng.random(nl),
+                         lig_s=0.005 + 0.01 * rng.random(nl), lig_gamma=0.005 + 0.01 * rng.random(nl), lig_D=1e-6 * (1 + rng.random(nl)),
+                         grp_alpha=[1500.0, 1200.0, 1800.0], grp_beta=[5.56e-4, -3e-4, 2e-4])
+
+
 def _state(cfg, seed, amp=90.0):
     rng = np.random.default_rng(seed)
     rho = 9000.0 + amp * rng.standard_normal(cfg.N)
     return np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1 + 0.01 * rng.standard_normal(cfg.N)) for l in range(cfg.nlig)])
 
 
-@pytest.mark.parametrize('shape,nlig', [((64, 32), 1), ((32, 128), 2), ((256, 512), 1), ((64, 64), 3), ((8192, 32), 1), ((32, 4096), 1)])
+@pytest.mark.parametrize('shape,nlig', [((64, 32), 1), ((32, 128), 2), ((256, 512), 1), ((64, 64), 3), ((8192, 32), 1), ((32, 4096), 1),
+                                        ((64, 64), 5), ((32, 64), 12)])
 @pytest.mark.parametrize('h', [0.02, 5.0])
 def test_spectral_operator_vs_numpy(shape, nlig, h):
     L = tuple(n * 4.0 / 1536 for n in shape)
-    cfg = _three_ligands(shape, L) if nlig == 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
+    cfg = _three_ligands(shape, L) if nlig == 3 else _many_ligands(2, shape, L, nlig) if nlig > 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
     u = _state(cfg, 3)
     v = np.random.default_rng(4).standard_normal(u.size)
     shift = 1.0 / (GAMMA * h)
@@ -174,10 +183,11 @@ def _numpy_spectral3d(cfg, u, shift, v):
     return np.real(np.fft.ifftn(np.array(zs), axes=(1, 2, 3))).reshape(-1)
 
 
-@pytest.mark.parametrize('shape,nlig', [((32, 32, 32), 1), ((64, 32, 128), 2), ((32, 64, 32), 1)])
+@pytest.mark.parametrize('shape,nlig', [((32, 32, 32), 1), ((64, 32, 128), 2), ((32, 64, 32), 1), ((32, 32, 32), 4)])
 @pytest.mark.parametrize('h', [0.02, 5.0])
 def test_spectral_operator_3d_vs_numpy(shape, nlig, h):
-    cfg = ProblemConfig.standard(3, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=nlig)
+    L = tuple(n * 4.0 / 1536 for n in shape)
+    cfg = _many_ligands(3, shape, L, nlig) if nlig > 2 else ProblemConfig.standard(3, shape, L=L, nlig=nlig)
     u = _state(cfg, 3)
     v = np.random.default_rng(4).standard_normal(u.size)
     shift = 1.0 / (GAMMA * h)
