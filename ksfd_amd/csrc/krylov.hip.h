@@ -460,6 +460,10 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
         }
         rn = sqrt(h->hres[0]);
         ls->its++;
+        {
+            static const bool trace = getenv("KSFD_SPEC_TRACE") != nullptr;        // residual history of the defect correction (diagnostics)
+            if (trace) fprintf(stderr, "[spec] sweep %d rel %.3e%s\n", k, rn / bn, (k == 0 && guess) ? " (guess)" : "");
+        }
         if (!(rn == rn)) return fail(h, KSFD_ENAN, "spectral solve: residual is not finite");
         if (rn <= tol) { ls->rel = rn / bn; return KSFD_OK; }
         if (rn > 0.25 * rprev) { slow = true; break; }
