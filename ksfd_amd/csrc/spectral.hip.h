@@ -591,6 +591,103 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     }
 }
 
+// Column kernel for field counts whose 2*npair columns do not fit the LDS together (8192^2 x 3 fields needs 278 KB): two launches
+// over blocks (column pair, FIELD pair = blockIdx.y), each holding only its own two columns.
+//   phase 1: forward transform, the spectrum written to W in column layout (read from the tiles Wt when lg_rb >= 0, else in place)
+//   phase 2: the block's two columns of the spectrum back into the LDS; the symbol stage takes the OTHER field pairs' values straight
+//            from W (contiguous along y in both walking directions); inverse transform; result to Wout -- a different array, since
+//            the blocks of the other field pairs still read W
+// 2 + (npair + 2) passes over a pair's columns instead of 2: the price of keeping the solver at all for such sizes.
+template <int NL>
+__device__ __forceinline__ void kspec_cols_symbol_split(const KFFTPlan &PY, kcf *lds, int sstride, bool self, int kxA, int kxB, int p0, const kcf *__restrict__ W,
+                                                        int nxl, int lg_pl, long long pstride, int jA, int jB, const int *__restrict__ posy,
+                                                        const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly, const KSpecSym &S)
+{
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int ny = PY.n, half = ny >> 1, plmask = (1 << lg_pl) - 1;
+    const int nitem = self ? 2 * ny : ny;
+    auto at = [&](int p, int c, int y) {
+        return W + (long long)(y >> lg_pl) * pstride + (((long long)p * nxl + (c ? jB : jA)) << lg_pl) + (y & plmask);
+    };
+    for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
+        const int mpos = item & (ny - 1);
+        const int ky = kyofpos[mpos];
+        int ca = 0, cb = 1;
+        if (self) { ca = cb = item >> PY.lg; if (ky > half) continue; }
+        const int kym = (ny - ky) & (ny - 1);
+        const int mposp = posy[kym];
+        const int m = kspec_pad(mpos), mp = kspec_pad(mposp);
+        const float L2 = lx[ca ? kxB : kxA] + ly[ky];
+        kcf a[npair], b[npair];
+#pragma unroll
+        for (int p = 0; p < npair; p++) {
+            if (p == p0) { a[p] = lds[ca * sstride + m]; b[p] = lds[cb * sstride + mp]; }
+            else { a[p] = *at(p, ca, mpos); b[p] = *at(p, cb, mposp); }
+        }
+        kspec_symbol<NL>(S, L2, a, b);
+        kcf ra = a[0], rb = b[0];
+#pragma unroll
+        for (int p = 1; p < npair; p++) if (p == p0) { ra = a[p]; rb = b[p]; }
+        lds[ca * sstride + m] = ra; lds[cb * sstride + mp] = rb;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ Wt, int lg_rb,
+                                                         kcf *__restrict__ Wout, const kcf *__restrict__ tw, const int4 *__restrict__ pairtab, const int *__restrict__ posy,
+                                                         const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
+{
+    extern __shared__ kcf kspec_lds[];
+    const int ny = PY.n, p0 = blockIdx.y;
+    const int4 pt = pairtab[kspec_tile(blockIdx.x, gridDim.x)];
+    const bool self = pt.w != 0;
+    const int jA = pt.x, jB = pt.y, kxA = pt.z, kxB = self ? pt.w - 1 : pt.z;
+    const int sstride = ny + (ny >> 4) + 1;
+    const int half = ny >> 1, lg_half = PY.lg - 1;
+    const int plmask = (1 << lg_pl) - 1;
+    auto colat = [&](kcf *base, int c, int y) {                // y even: a float4 never straddles two pieces
+        return base + (long long)(y >> lg_pl) * pstride + (((long long)p0 * nxl + (c ? jB : jA)) << lg_pl) + (y & plmask);
+    };
+    // both phases start by filling the LDS with the block's two columns
+    for (int base = 0; base < 2 * half; base += 8 * blockDim.x) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < 2 * half) {
+                const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
+                t[u] = (phase == 1 && lg_rb >= 0)
+                           ? *reinterpret_cast<const float4 *>(Wt + ((((long long)p0 * (ny >> lg_rb) + (y >> lg_rb)) * nxl + (c ? jB : jA)) << lg_rb) + (y & ((1 << lg_rb) - 1)))
+                           : *reinterpret_cast<const float4 *>(colat(W, c, y));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * blockDim.x + threadIdx.x;
+            if (idx < 2 * half) {
+                const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
+                kcf *q = kspec_lds + c * sstride;
+                q[kspec_pad(y)] = make_float2(t[u].x, t[u].y);
+                q[kspec_pad(y + 1)] = make_float2(t[u].z, t[u].w);
+            }
+        }
+    }
+    __syncthreads();
+    kcf *dst = W;
+    if (phase == 1) kspec_fft_fwd(PY, kspec_lds, sstride, 2, tw);
+    else {
+        KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol_split<NL>(PY, kspec_lds, sstride, self, kxA, kxB, p0, W, nxl, lg_pl, pstride, jA, jB, posy, kyofpos, lx, ly, S)));
+        __syncthreads();
+        kspec_fft_inv(PY, kspec_lds, sstride, 2, tw);
+        dst = Wout;
+    }
+    for (int idx = threadIdx.x; idx < 2 * half; idx += blockDim.x) {
+        const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
+        const kcf *q = kspec_lds + c * sstride;
+        const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
+        *reinterpret_cast<float4 *>(colat(dst, c, y)) = make_float4(c0.x, c0.y, c1.x, c1.y);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3-D (one rank): x rows as above over the nz*ny rows (tile-major store), then
 //   k_spec3_y_fwd : one block per (pos_x, CZ consecutive z): gathers CZ columns over y from the tiles, DIF along y, stores

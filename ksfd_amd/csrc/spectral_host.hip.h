@@ -160,13 +160,16 @@ static void spec_build(ksfd_handle *h)
     S.rb = rb;
     S.lds_rows = row_bytes * rb;
     S.lds_cols = sizeof(kcf) * (size_t)(ny + (ny >> 4) + 1) * 2 * S.npair;
+    S.cols_split = S.lds_cols > lds_max - 1024 || (getenv("KSFD_SPEC_SPLIT") && S.npair > 1);      // (the knob: tests of the split path on small grids)
+    if (S.cols_split) S.lds_cols = sizeof(kcf) * (size_t)(ny + (ny >> 4) + 1) * 2;                  // one field pair per block
     if (S.lds_cols > lds_max - 1024) return;
     if (hipFuncSetAttribute((const void *)k_spec_rows_fwd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess) { hipGetLastError(); return; }
     {
         hipError_t e = hipSuccess;
-        e = hipFuncSetAttribute((const void *)k_spec_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols);
+        e = S.cols_split ? hipFuncSetAttribute((const void *)k_spec_cols_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols)
+                         : hipFuncSetAttribute((const void *)k_spec_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
     auto twiddles = [](int n) {
@@ -206,7 +209,7 @@ static void spec_build(ksfd_handle *h)
     const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nyl;
     S.nyp = (int)nyl;
     S.tile_major = P == 1 && rb >= 2 && !getenv("KSFD_SPEC_TRANSPOSED");
-    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || ((P > 1 || S.tile_major) && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
+    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || ((P > 1 || S.tile_major || S.cols_split) && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
         !spec_upload(&S.twx, twiddles(S.px.n)) || !spec_upload(&S.twy, twiddles(S.py.n)) ||
         !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) || !spec_upload(&S.pairtab, pairs) ||
         !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1]))) { hipGetLastError(); spec_free(h); return; }
@@ -223,8 +226,15 @@ static void spec_build(ksfd_handle *h)
                     (void)dme;
                     S.a2a_fwd_s.push_back({ q, mine_for_q, pbytes });
                     S.a2a_fwd_r.push_back({ q, from_q, pbytes });
+                    if (S.cols_split) {
+                        // phase 2 of the split column kernel leaves its result in W (used as scratch in the layout of W2); it comes
+                        // home into W2 (in the layout of W), which is where the inverse row kernel then reads
+                        S.a2a_bwd_s.push_back({ q, S.W + (from_q - S.W2), pbytes });
+                        S.a2a_bwd_r.push_back({ q, S.W2 + (back_mine - S.W), pbytes });
+                    } else {
                     S.a2a_bwd_s.push_back({ q, from_q, pbytes });
                     S.a2a_bwd_r.push_back({ q, back_mine, pbytes });
+                    }
                 }
     }
     S.ok = true;
@@ -290,7 +300,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     px_f.flags = py_c.flags = px_i.flags = fuse;
     int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
     if (getenv("KSFD_SPEC_THRR")) thr_rows = atoi(getenv("KSFD_SPEC_THRR"));
-    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * S.npair * ny_glob / 16));
+    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * (S.cols_split ? 1 : S.npair) * ny_glob / 16));
     if (getenv("KSFD_SPEC_THRC")) thr_cols = atoi(getenv("KSFD_SPEC_THRC"));
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
@@ -326,10 +336,18 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         Wc = S.W2;
     }
     {
-        Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);                                 // work array in place
+        Scope sc(h, KC_SPECTRAL, S.cols_split ? (4.0 + S.npair) * pn : 2.0 * pn, 0.0);      // work array in place (split: 2 + (npair + 2) passes)
         const long long pstride = (long long)S.npair * S.nxl << S.lg_pl;
         int lg_rb = 0;
         while ((1 << lg_rb) < S.rb) lg_rb++;
+        if (S.cols_split) {
+            // one rank: tiles (W2) -> spectrum (W) -> result (W2); slab ranks: in place in W2, then result into W as scratch
+            kcf *spec = h->size > 1 ? S.W2 : S.W, *res = h->size > 1 ? S.W : S.W2;
+            for (int phase = 1; phase <= 2; phase++)
+                hipLaunchKernelGGL(k_spec_cols_split, dim3((unsigned)S.nblk_cols, (unsigned)S.npair), dim3(thr_cols), S.lds_cols, h->st, phase, py_c, S.nxl, S.lg_pl, pstride, spec,
+                                   (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, res, (const kcf *)S.twy,
+                                   (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
+        } else
         hipLaunchKernelGGL(k_spec_cols, dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy,
                            (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
     }
@@ -340,7 +358,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     }
     {
         Scope sc(h, KC_SPECTRAL, pn + 8.0 * (1 + add.n) * fn, 8.0 * (1 + add.n) * fn);     // read W (+ x / guess vectors) | write z
-        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)(d3 ? S.W2 : S.W), z + goff, G.plane, (const kcf *)S.twx, add);
+        hipLaunchKernelGGL(k_spec_rows_inv, dim3(ntiles, S.npair), dim3(thr_rows), S.lds_rows, h->st, px_i, S.nyp, S.rb, ntiles, G.F, (const kcf *)((d3 || S.cols_split) ? S.W2 : S.W), z + goff, G.plane, (const kcf *)S.twx, add);
     }
     HIPCHK(h, hipGetLastError());
     return KSFD_OK;

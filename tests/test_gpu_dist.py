@@ -207,11 +207,14 @@ def _spectral_worker(rank, size, port, shape, nlig, outfile):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('size,shape,nlig', [(2, (64, 64), 1), (4, (128, 64), 2), (2, (32, 256), 3)])
-def test_slab_distributed_spectral_solver_matches_single_rank(size, shape, nlig, tmp_path):
+@pytest.mark.parametrize('size,shape,nlig,split', [(2, (64, 64), 1, False), (4, (128, 64), 2, False), (2, (32, 256), 3, False), (2, (64, 128), 2, True),
+                                                   (4, (32, 64), 3, True)])
+def test_slab_distributed_spectral_solver_matches_single_rank(size, shape, nlig, split, tmp_path, monkeypatch):
     """the y-transforms of the spectral preconditioner across slab ranks (all-to-all transposes, columns of {kx, -kx} pairs kept on
     one rank): same operator as on one rank (fp32 FFTs: summation order differs, 1e-5), and a step solved with it is the single-rank
     step to the solver tolerance"""
+    if split:       # the two-phase column kernel (field pairs that do not fit the LDS together), forced on a small grid; the ranks inherit the knob
+        monkeypatch.setenv('KSFD_SPEC_SPLIT', '1')
     outfile = str(tmp_path / 'result.npz')
     mp.spawn(_spectral_worker, args=(size, _free_port(), shape, nlig, outfile), nprocs=size, join=True)
     z = np.load(outfile)

@@ -96,8 +96,8 @@ def _tile(x, F, small_shape, reps):
 
 
 @pytest.mark.parametrize('small,reps,nlig,hs', [
-    ((1024, 1024), 8, 2, (1e-3, 0.1)),      # BASELINE configs[3]: 8192^2, 3 fields; h = 1e-3 plain GMRES, h = 0.1 polynomial regime (X ~ 19)
-    ((64, 64, 64), 8, 1, (1e-3, 0.05)),     # BASELINE configs[4]: 512^3, 2 fields, 13-point star
+    ((1024, 1024), 8, 2, (1e-3, 0.1)),      # BASELINE configs[3]: 8192^2, 3 fields; h = 1e-3 plain GMRES, h = 0.1 (X ~ 19) spectral solver, two-phase column kernel
+    ((64, 64, 64), 8, 1, (1e-3, 0.05)),     # BASELINE configs[4]: 512^3, 2 fields, 13-point star; second step with the 3-D spectral solver
 ])
 def test_full_size_configs_are_tilings_of_small_ones(small, reps, nlig, hs):
     """RHS, Jacobian action and whole implicit steps of the 8192^2 x 3 and 512^3 problems equal the periodic tiling of the
@@ -137,6 +137,8 @@ def test_full_size_configs_are_tilings_of_small_ones(small, reps, nlig, hs):
     for i, h in enumerate(hs):
         t, _, st, rc = kb.step(t, h, opts)
         assert st.accepted
+        if i == 1:
+            assert st.pc_used & 8                 # the full-size problem took the spectral solver (pc_type 2 = automatic)
         assert abs(st.wrms - want['wrms%d' % i]) <= 1e-6 * want['wrms%d' % i]
         got = kb.get_state()
         assert rel_l2(got, _tile(want['step%d' % i], F, small, reps)) < 1e-10, (i, h)

@@ -106,6 +106,31 @@ def test_spectral_operator_vs_numpy(shape, nlig, h):
     assert rel_l2(got, want) < 2e-5              # fp32 FFTs and symbol; it is a preconditioner
 
 
+@pytest.mark.parametrize('shape,nlig,forced', [((32, 8192), 2, False), ((64, 128), 2, True), ((64, 64), 3, True), ((32, 64), 5, True)])
+def test_spectral_split_column_kernel_vs_numpy(shape, nlig, forced, monkeypatch):
+    """more field pairs than the LDS holds columns for (8192 rows x 3 fields: 278 KB): the column pass runs as two launches over
+    (column pair, field pair) blocks, the symbol stage reading the other field pairs' spectra from memory; KSFD_SPEC_SPLIT forces
+    that path on small grids"""
+    if forced:
+        monkeypatch.setenv('KSFD_SPEC_SPLIT', '1')
+    L = tuple(n * 4.0 / 1536 for n in shape)
+    cfg = _three_ligands(shape, L) if nlig == 3 else _many_ligands(2, shape, L, nlig) if nlig > 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
+    u = _state(cfg, 3)
+    v = np.random.default_rng(4).standard_normal(u.size)
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    for h in (0.02, 5.0):
+        shift = 1.0 / (GAMMA * h)
+        assert rel_l2(k.spectral_apply(shift, v), _numpy_spectral(cfg, u, shift, v)) < 2e-5
+    # and through a whole step (defect correction on top of it) against the sparse-LU step
+    t, hn, st, rc = k.step(0.0, 0.3, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=4))
+    assert st.pc_used & 8
+    if cfg.N <= 64 * 128:
+        un, _ = _lu_step(cfg, u, 0.3, 0.01, 1e-6)
+        assert rel_l2(k.get_state(), un) < 1e-9
+    k.close()
+
+
 def test_spectral_unavailable_is_reported():
     cfg = ProblemConfig.standard(2, (48, 40), L=(0.1, 0.1))             # not powers of two
     k = klib.KSFDHip(cfg)
