@@ -945,7 +945,7 @@ extern "C" int ksfd_spectral_apply(ksfd_handle *h, double shift, const double *v
 {
     if (!h || !vh || !outh || !(shift > 0.0)) return KSFD_EINVAL;
     hipSetDevice(h->device);
-    if (!h->spec.ok) return fail(h, KSFD_EINVAL, "spectral preconditioner not available for this handle (needs 2-D, one rank, power-of-two extents)");
+    if (!h->spec.ok) return fail(h, KSFD_EINVAL, "spectral preconditioner not available for this handle (needs power-of-two extents of 32 ... 16384 points; 1, 2, 4 or 8 slab ranks with an all-to-all transport)");
     int rc;
     if ((rc = upload(h, vh, layout, h->t2))) return rc;
     if ((rc = ensure_coef(h))) return rc;

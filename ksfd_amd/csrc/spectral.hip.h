@@ -769,7 +769,9 @@ __device__ __forceinline__ void kspec3_z_symbol(const KFFTPlan &PZ, kcf *kspec_l
 }
 
 // pairtab[e] = (column A, column B, kx | ky << 16, self) with column = pos_x * ny + pos_y; self: A == B is its own partner
-__global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb, long long ncol, kcf *__restrict__ W2, const kcf *__restrict__ tw,
+// Column storage as in k_spec_cols: a column consists of nz >> lg_pl pieces of 2^lg_pl elements, `pstride` elements apart (one piece
+// per z-slab rank after the all-to-all; a single piece on one rank).
+__global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb, long long ncol, int lg_pl, long long pstride, kcf *__restrict__ W2, const kcf *__restrict__ tw,
                                                   const int4 *__restrict__ pairtab, const int *__restrict__ posz, const int *__restrict__ kzofpos,
                                                   const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, KSpecSym S)
 {
@@ -781,14 +783,16 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
     const int ne = min(pb, nent - e0);
     const int nseq = 2 * npair * ne;                              // sequence s = (slot*npair + p)*2 + c
     const int half = nz >> 1, lg_half = PZ.lg - 1;
-    auto colptr = [&](int s) {
+    const int plmask = (1 << lg_pl) - 1;
+    auto colptr = [&](int s) {                                     // start of the column's FIRST piece
         const int c = s & 1, p = (s >> 1) % npair, slot = (s >> 1) / npair;
         const int4 pt = pairtab[e0 + slot];
-        return W2 + ((long long)p * ncol + (c ? pt.y : pt.x)) * nz;
+        return W2 + (((long long)p * ncol + (c ? pt.y : pt.x)) << lg_pl);
     };
+    auto zoff = [&](int z) { return (long long)(z >> lg_pl) * pstride + (z & plmask); };      // z even: a float4 never straddles two pieces
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
         const int s = idx >> lg_half, z = 2 * (idx & (half - 1));
-        const float4 t = *reinterpret_cast<const float4 *>(colptr(s) + z);
+        const float4 t = *reinterpret_cast<const float4 *>(colptr(s) + zoff(z));
         kcf *q = kspec_lds + s * sstride;
         q[kspec_pad(z)] = make_float2(t.x, t.y);
         q[kspec_pad(z + 1)] = make_float2(t.z, t.w);
@@ -803,7 +807,7 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
         if ((s & 1) && pairtab[e0 + (s >> 1) / npair].w) continue;      // the B slot of a self column is a copy
         const kcf *q = kspec_lds + s * sstride;
         const kcf c0 = q[kspec_pad(z)], c1 = q[kspec_pad(z + 1)];
-        *reinterpret_cast<float4 *>(colptr(s) + z) = make_float4(c0.x, c0.y, c1.x, c1.y);
+        *reinterpret_cast<float4 *>(colptr(s) + zoff(z)) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
 

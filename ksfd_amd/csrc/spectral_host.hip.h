@@ -63,18 +63,25 @@ static std::vector<float> spec_symbol_table(int n, double inv_h2)
     return l;
 }
 
-// 3-D, one rank (see spectral.hip.h): plans per axis, the column-pair table of the z kernel, two work arrays
+// 3-D (see spectral.hip.h): plans per axis, the column-pair table of the z kernel, two work arrays.  z-slab ranks (P = 2, 4, 8): the
+// x and y transforms are local (a rank owns whole z planes); for the z transforms every rank needs whole z columns, so
+// W[pair][pos_x][pos_y][z_local] is redistributed by an all-to-all over pos_x exactly as in 2-D (same digit ownership: the columns
+// (kx, ky) and (-kx, -ky) land on one rank), a received column consisting of P pieces of nz/P elements.
 static void spec_build3d(ksfd_handle *h)
 {
     SpecState &S = h->spec;
     const KGeom &G = h->G;
-    if (h->size != 1 || G.ng != 0 || getenv("KSFD_SPEC_NO3D")) return;
-    if (!spec_plan(G.nx, S.px) || !spec_plan(G.ny, S.py) || !spec_plan(G.nz, S.pz)) return;
-    if (S.px.radix[0] != 16 || G.nx > 32768 || G.ny > 32768) return;
+    const int P = h->size;
+    if (getenv("KSFD_SPEC_NO3D")) return;
+    if (P == 1 && G.ng != 0) return;
+    if (P > 1 && (!h->tr || !h->tr->has_alltoall() || (P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
+    const long long nzg = h->cfg.n[2], nzl = G.sloc;               // global / local z planes
+    if (!spec_plan(G.nx, S.px) || !spec_plan(G.ny, S.py) || !spec_plan(nzg, S.pz)) return;
+    if (S.px.radix[0] != 16 || G.nx > 32768 || G.ny > 32768 || (nzl & (nzl - 1)) || nzl < 2) return;
     S.dim = 3;
     S.npair = (G.F + 1) / 2;
     const size_t lds_max = 160 * 1024 - 1024;
-    const long long nrows = G.ny * G.nz;
+    const long long nrows = G.ny * nzl;
     const size_t row_bytes = sizeof(kcf) * (size_t)(G.nx + (G.nx >> 4) + 1);
     int rb = 16;
     while (rb > 1 && row_bytes * rb > lds_max) rb >>= 1;
@@ -84,9 +91,9 @@ static void spec_build3d(ksfd_handle *h)
     S.nyp = (int)nrows;                                            // column stride of the array the inverse row kernel reads
     S.lg_rb3 = 0; while ((1 << S.lg_rb3) < rb) S.lg_rb3++;
     S.lds_rows = row_bytes * rb;
-    const size_t ycol = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * S.npair, zcol = sizeof(kcf) * (size_t)(G.nz + (G.nz >> 4) + 1) * 2 * S.npair;
+    const size_t ycol = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * S.npair, zcol = sizeof(kcf) * (size_t)(nzg + (nzg >> 4) + 1) * 2 * S.npair;
     int cz = 16;
-    while (cz > 1 && (ycol * cz > lds_max / 2 || G.nz % cz)) cz >>= 1;      // <= half the LDS: two blocks per CU
+    while (cz > 1 && (ycol * cz > lds_max / 2 || nzl % cz)) cz >>= 1;      // <= half the LDS: two blocks per CU
     if (ycol * cz > lds_max) return;
     S.lg_cz = 0; while ((1 << S.lg_cz) < cz) S.lg_cz++;
     S.lds_y3 = ycol * cz;
@@ -104,19 +111,28 @@ static void spec_build3d(ksfd_handle *h)
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_z, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
-    // pairs of columns {(kx,ky), (-kx,-ky)}; a column is addressed by its position pair
-    const int nx = (int)G.nx, ny = (int)G.ny;
+    // ownership of the x positions (as in 2-D): top digit -> (rank, index of the digit in that rank's list)
+    const int nx = (int)G.nx, ny = (int)G.ny, nx16 = nx / 16, ndig = 16 / P;
+    int dig_rank[16], dig_idx[16];
+    for (int q = 0; q < P; q++) for (int di = 0; di < ndig; di++) { const int d = spec_digit_order[q * ndig + di]; dig_rank[d] = q; dig_idx[d] = di; }
+    S.nxl = nx / P;
+    S.lg_pl = 0;
+    while ((1LL << S.lg_pl) < nzl) S.lg_pl++;
+    auto local_index = [&](int j) { return P == 1 ? j : dig_idx[j / nx16] * nx16 + (j % nx16); };
+    // pairs of columns {(kx,ky), (-kx,-ky)}; a column is addressed by its (local) position pair
     const std::vector<int> posx = spec_positions(S.px), posy = spec_positions(S.py);
     std::vector<int4> ent;
-    ent.reserve((size_t)nx * ny / 2 + 4);
-    for (int kx = 0; kx <= nx / 2; kx++)
+    ent.reserve((size_t)S.nxl * ny / 2 + 4);
+    for (int kx = 0; kx <= nx / 2; kx++) {
+        if (dig_rank[posx[kx] / nx16] != h->rank) continue;
         for (int ky = 0; ky < ny; ky++) {
             const int kxm = (nx - kx) % nx, kym = (ny - ky) % ny;
             const bool self = kxm == kx && kym == ky;
             if (!self && (kxm < kx || (kxm == kx && kym < ky))) continue;       // the partner comes first: it owns the pair
-            const int ca = posx[kx] * ny + posy[ky], cb = posx[kxm] * ny + posy[kym];
+            const int ca = local_index(posx[kx]) * ny + posy[ky], cb = local_index(posx[kxm]) * ny + posy[kym];
             ent.push_back(make_int4(ca, cb, kx | (ky << 16), self ? 1 : 0));
         }
+    }
     std::sort(ent.begin(), ent.end(), [](const int4 &a, const int4 &b) { return a.x < b.x; });
     S.nent = (int)ent.size();
     const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nrows;
@@ -126,11 +142,26 @@ static void spec_build3d(ksfd_handle *h)
         !spec_upload(&S.lx, spec_symbol_table(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, spec_symbol_table(S.py.n, h->P.inv_h2[1])) ||
         !spec_upload(&S.lz, spec_symbol_table(S.pz.n, h->P.inv_h2[2]))) { hipGetLastError(); spec_free(h); return; }
     // the z transforms need their own twiddle table when nz differs from ny: kept behind twy in one allocation is not worth it
-    if (G.nz != G.ny) {
+    if (nzg != G.ny) {
         kcf *tz = nullptr;
         if (!spec_upload(&tz, spec_twiddles(S.pz.n))) { hipGetLastError(); spec_free(h); return; }
         S.twz = tz;
     } else S.twz = S.twy;
+    if (P > 1) {
+        // pieces of the two all-to-alls: one per (peer, pair, top digit of the receiver) = nx/16 positions x ny x nzl, contiguous on both sides
+        const size_t pel = (size_t)nx16 * ny * nzl, pbytes = sizeof(kcf) * pel;
+        for (int q = 0; q < P; q++)
+            for (int p = 0; p < S.npair; p++)
+                for (int di = 0; di < ndig; di++) {
+                    const int dq = spec_digit_order[q * ndig + di];
+                    kcf *mine_for_q = S.W + ((size_t)p * nx + (size_t)dq * nx16) * ny * nzl;                          // my z planes of q's columns
+                    kcf *from_q = S.W2 + (((size_t)q * S.npair + p) * S.nxl + (size_t)di * nx16) * ny * nzl;          // q's z planes of my columns
+                    S.a2a_fwd_s.push_back({ q, mine_for_q, pbytes });
+                    S.a2a_fwd_r.push_back({ q, from_q, pbytes });
+                    S.a2a_bwd_s.push_back({ q, from_q, pbytes });
+                    S.a2a_bwd_r.push_back({ q, mine_for_q, pbytes });
+                }
+    }
     S.tile_major = true;
     S.ok = true;
 }
@@ -278,7 +309,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     Y.den_floor = (float)(0.02 * shift);
     for (int l = 0; l < h->P.nlig; l++) { Y.a_rU[l] = (float)S.a_rU[l]; Y.s[l] = (float)h->P.lig_s[l]; Y.gam[l] = (float)h->P.lig_gamma[l]; Y.D[l] = (float)h->P.lig_D[l]; }
     const bool d3 = S.dim == 3;
-    const int ntiles = (int)((d3 ? G.ny * G.nz : G.sloc) / S.rb);     // 3-D: the x rows are the nz*ny rows of the box
+    const int ntiles = (int)((d3 ? G.ny * G.sloc : G.sloc) / S.rb);     // 3-D: the x rows are the nz*ny rows of the box
     const long long goff = (long long)G.ng * G.inner;                // the row kernels address owned rows only
     KSpecLin ex, add;
     memset(&ex, 0, sizeof ex); memset(&add, 0, sizeof add);
@@ -310,21 +341,33 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     }
     if (d3) {
         const int cz = 1 << S.lg_cz;
+        const long long nzg = h->cfg.n[2], nzl = G.sloc;
         const int thr_y = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.npair * cz * G.ny / 16));
-        const int thr_z = (int)std::min<long long>(1024, std::max<long long>(256, (long long)2 * S.npair * S.pb * G.nz / 16));
+        const int thr_z = (int)std::min<long long>(1024, std::max<long long>(256, (long long)2 * S.npair * S.pb * nzg / 16));
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
-            hipLaunchKernelGGL(k_spec3_y_fwd, dim3((unsigned)(G.nz / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)G.nz, S.lg_cz, S.npair, S.lg_rb3,
+            hipLaunchKernelGGL(k_spec3_y_fwd, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)nzl, S.lg_cz, S.npair, S.lg_rb3,
                                (const kcf *)S.W2, S.W, (const kcf *)S.twy);
         }
-        {
-            Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
-            hipLaunchKernelGGL(k_spec3_z, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)G.nx * G.ny, S.W,
-                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y);
+        kcf *Wz = S.W;
+        if (h->size > 1) {                                            // z planes of everybody's columns -> whole z columns of mine
+            Scope sc(h, KC_HALO, pn);
+            if (h->tr->alltoall(S.a2a_fwd_s, S.a2a_fwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
+            Wz = S.W2;
         }
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
-            hipLaunchKernelGGL(k_spec3_y_inv, dim3((unsigned)(G.nz / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)G.nz, S.lg_cz, S.npair,
+            const long long pstride = (long long)S.npair * S.nxl * G.ny << S.lg_pl;
+            hipLaunchKernelGGL(k_spec3_z, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)S.nxl * G.ny, S.lg_pl, pstride, Wz,
+                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y);
+        }
+        if (h->size > 1) {
+            Scope sc(h, KC_HALO, pn);
+            if (h->tr->alltoall(S.a2a_bwd_s, S.a2a_bwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
+        }
+        {
+            Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
+            hipLaunchKernelGGL(k_spec3_y_inv, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)nzl, S.lg_cz, S.npair,
                                (const kcf *)S.W, S.W2, (const kcf *)S.twy);
         }
         // the inverse x rows read W3 = S.W2 ([pair][pos_x][z*ny + y]) below

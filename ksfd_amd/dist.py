@@ -192,17 +192,24 @@ def spectral_selftest(ks, cfg, rank, size, shift=2.0, tol=2e-3):
     coefficient operator it inverts IS the Jacobian, so A (M^-1 v) must give v back (to fp32 accuracy) for a smooth v.  True where
     the handle has no spectral solver (nothing to check)."""
     dim = cfg.dim
-    if dim != 2:
+    if dim not in (2, 3):
         return True
-    lo, hi = slab_range(cfg.n[1], rank, size)
+    lo, hi = slab_range(cfg.n[dim - 1], rank, size)
     nx, ny = cfg.n[0], cfg.n[1]
-    nloc = (hi - lo) * nx
+    nloc = (hi - lo) * nx * (ny if dim == 3 else 1)
     ks.set_state(np.concatenate([np.full(nloc, 9000.0)] + [np.full(nloc, 9000.0 * cfg.lig_s[l] / cfg.lig_gamma[l]) for l in range(cfg.nlig)]))
-    x = np.arange(nx)[None, :] / nx
-    y = np.arange(lo, hi)[:, None] / ny
     planes = []
-    for c in range(cfg.F):
-        planes.append((np.cos(2 * np.pi * (3 * x + (2 + c) * y)) + 0.5 * np.sin(2 * np.pi * ((5 + c) * x - 7 * y)) + 0.25).reshape(-1))
+    if dim == 2:
+        x = np.arange(nx)[None, :] / nx
+        y = np.arange(lo, hi)[:, None] / ny
+        for c in range(cfg.F):
+            planes.append((np.cos(2 * np.pi * (3 * x + (2 + c) * y)) + 0.5 * np.sin(2 * np.pi * ((5 + c) * x - 7 * y)) + 0.25).reshape(-1))
+    else:
+        x = np.arange(nx)[None, None, :] / nx
+        y = np.arange(ny)[None, :, None] / ny
+        z = np.arange(lo, hi)[:, None, None] / cfg.n[2]
+        for c in range(cfg.F):
+            planes.append((np.cos(2 * np.pi * (3 * x + (2 + c) * y - 2 * z)) + 0.5 * np.sin(2 * np.pi * ((5 + c) * x - 3 * y + 5 * z)) + 0.25).reshape(-1))
     v = np.concatenate(planes)
     try:
         z = ks.spectral_apply(shift, v)
