@@ -225,7 +225,7 @@ __device__ __forceinline__ void kspec_stage0_inv_to(const kcf *lds, int sstride,
     KSPEC_LGS_DISPATCH(lg_n - 4, (kspec_stage0_inv_to_t<LGS>(lds, sstride, nseq, tw, st)));
 }
 
-// plans are radix 16 from the top with one smaller last stage (spec_plan), so a radix below 16 only ever runs at S = 1
+// plans are radix 16 from the top with one smaller last stage, or [.., 8, 4] (spec_plan): a radix below 16 runs at S = 1, radix 8 also at S = 4
 template <bool INV>
 __device__ __forceinline__ void kspec_stage_any(int radix, kcf *lds, int sstride, int nseq, int lg_n, int lg_L, const kcf *__restrict__ tw)
 {
@@ -244,7 +244,7 @@ __device__ __forceinline__ void kspec_stage_any(int radix, kcf *lds, int sstride
         default: kspec_stage<16, INV, 10>(lds, sstride, nseq, lg_n, tw); break;      // n = 16384, the largest spec_plan accepts
         }
     }
-    else if (radix == 8) kspec_stage<8, INV, 0>(lds, sstride, nseq, lg_n, tw);
+    else if (radix == 8) { if (lg_L == 3) kspec_stage<8, INV, 0>(lds, sstride, nseq, lg_n, tw); else kspec_stage<8, INV, 2>(lds, sstride, nseq, lg_n, tw); }      // S = 1, or S = 4 in [.., 8, 4]
     else if (radix == 4) kspec_stage<4, INV, 0>(lds, sstride, nseq, lg_n, tw);
     else kspec_stage<2, INV, 0>(lds, sstride, nseq, lg_n, tw);
 }
@@ -696,6 +696,20 @@ __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY
 //   k_spec3_y_inv : reads CZ-z segments of W2, DIT inverse along y, stores W3[pair][pos_x][z*ny + y] (contiguous runs of ny)
 // and the inverse x rows over W3.  HBM traffic 48 F N bytes per application (five kernels, four passes over the work arrays).
 // ---------------------------------------------------------------------------------------------
+// global -> LDS staging in batches of 8 items per thread: all loads of a batch are issued before the first LDS store (one memory
+// latency per batch instead of one per item; the plain loop left it to the compiler, which kept them in order)
+template <typename T, typename LD, typename ST>
+__device__ __forceinline__ void kspec_stage_in(int total, LD ld, ST st)
+{
+    for (int base = 0; base < total; base += 8 * blockDim.x) {
+        T t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = base + u * blockDim.x + threadIdx.x; if (idx < total) t[u] = ld(idx); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int idx = base + u * blockDim.x + threadIdx.x; if (idx < total) st(idx, t[u]); }
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_spec3_y_fwd(KFFTPlan PY, int nx, int nz, int lg_cz, int npair, int lg_rb, const kcf *__restrict__ Wt,
                                                       kcf *__restrict__ W2, const kcf *__restrict__ tw)
 {
@@ -706,12 +720,12 @@ __global__ void __launch_bounds__(1024) k_spec3_y_fwd(KFFTPlan PY, int nx, int n
     const long long ntiles = ((long long)ny * nz) >> lg_rb;
     const int nseq = npair * cz;
     // sequence s = p*cz + zc ; element y
-    for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
+    kspec_stage_in<kcf>(nseq * ny, [&](int idx) {
         const int s = idx >> lg_ny, y = idx & (ny - 1);
         const int p = s >> lg_cz, zc = s & (cz - 1);
         const long long R = (long long)(z0 + zc) * ny + y;
-        kspec_lds[s * sstride + kspec_pad(y)] = Wt[(((long long)p * ntiles + (R >> lg_rb)) * nx + jx) * rb + (R & (rb - 1))];
-    }
+        return Wt[(((long long)p * ntiles + (R >> lg_rb)) * nx + jx) * rb + (R & (rb - 1))];
+    }, [&](int idx, kcf v) { kspec_lds[(idx >> lg_ny) * sstride + kspec_pad(idx & (ny - 1))] = v; });
     __syncthreads();
     kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
@@ -728,11 +742,15 @@ __global__ void __launch_bounds__(1024) k_spec3_y_inv(KFFTPlan PY, int nx, int n
     const int ny = PY.n, lg_ny = PY.lg, cz = 1 << lg_cz, jx = blockIdx.y, z0 = blockIdx.x * cz;
     const int sstride = ny + (ny >> 4) + 1;
     const int nseq = npair * cz;
-    for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
+    kspec_stage_in<kcf>(nseq * ny, [&](int idx) {
         const int zc = idx & (cz - 1), rest = idx >> lg_cz;
         const int jy = rest & (ny - 1), p = rest >> lg_ny;
-        kspec_lds[(p * cz + zc) * sstride + kspec_pad(jy)] = W2[(((long long)p * nx + jx) * ny + jy) * nz + z0 + zc];
-    }
+        return W2[(((long long)p * nx + jx) * ny + jy) * nz + z0 + zc];
+    }, [&](int idx, kcf v) {
+        const int zc = idx & (cz - 1), rest = idx >> lg_cz;
+        const int jy = rest & (ny - 1), p = rest >> lg_ny;
+        kspec_lds[(p * cz + zc) * sstride + kspec_pad(jy)] = v;
+    });
     __syncthreads();
     kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     const long long nrows = (long long)ny * nz;
@@ -790,13 +808,15 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
         return W2 + (((long long)p * ncol + (c ? pt.y : pt.x)) << lg_pl);
     };
     auto zoff = [&](int z) { return (long long)(z >> lg_pl) * pstride + (z & plmask); };      // z even: a float4 never straddles two pieces
-    for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
+    kspec_stage_in<float4>(nseq * half, [&](int idx) {
         const int s = idx >> lg_half, z = 2 * (idx & (half - 1));
-        const float4 t = *reinterpret_cast<const float4 *>(colptr(s) + zoff(z));
+        return *reinterpret_cast<const float4 *>(colptr(s) + zoff(z));
+    }, [&](int idx, float4 t) {
+        const int s = idx >> lg_half, z = 2 * (idx & (half - 1));
         kcf *q = kspec_lds + s * sstride;
         q[kspec_pad(z)] = make_float2(t.x, t.y);
         q[kspec_pad(z + 1)] = make_float2(t.z, t.w);
-    }
+    });
     __syncthreads();
     kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw);
     KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S)));

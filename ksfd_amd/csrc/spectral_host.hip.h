@@ -9,8 +9,12 @@ static bool spec_plan(long long n, KFFTPlan &P)
     while ((1LL << lg) < n) lg++;
     P.n = (int)n; P.lg = lg; P.nstage = 0; P.flags = 0;
     int left = lg;
-    const int lgmax = 4;         // radix 16 from the top, one smaller last stage (kspec_stage_any relies on exactly this shape)
-    while (left >= lgmax && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << lgmax; left -= lgmax; }
+    // radix 16 from the top, then one smaller stage -- except that a trailing [16, 2] becomes [8, 4]: a radix-2 stage costs a full LDS
+    // pass and a barrier for a quarter of the work (512 = 16*8*4, 8192 = 16*16*8*4).  kspec_stage_any relies on exactly these shapes.
+    // (n = 32 stays [16, 2]: the row kernels and the slab ownership want a leading radix 16)
+    if (lg == 5) { P.radix[P.nstage++] = 16; P.radix[P.nstage++] = 2; left = 0; }
+    while (left >= 4 && left != 5 && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 16; left -= 4; }
+    if (left == 5) { P.radix[P.nstage++] = 8; P.radix[P.nstage++] = 4; left = 0; }
     if (left && P.nstage < KSPEC_MAXSTAGE) { P.radix[P.nstage++] = 1 << left; left = 0; }
     return left == 0;
 }
@@ -94,11 +98,13 @@ static void spec_build3d(ksfd_handle *h)
     const size_t ycol = sizeof(kcf) * (size_t)(G.ny + (G.ny >> 4) + 1) * S.npair, zcol = sizeof(kcf) * (size_t)(nzg + (nzg >> 4) + 1) * 2 * S.npair;
     int cz = 16;
     while (cz > 1 && (ycol * cz > lds_max / 2 || nzl % cz)) cz >>= 1;      // <= half the LDS: two blocks per CU
+    if (getenv("KSFD_SPEC_CZ")) cz = std::max(1, std::min(cz, atoi(getenv("KSFD_SPEC_CZ"))));        // experiment knob
     if (ycol * cz > lds_max) return;
     S.lg_cz = 0; while ((1 << S.lg_cz) < cz) S.lg_cz++;
     S.lds_y3 = ycol * cz;
     int pb = 16;
-    while (pb > 1 && zcol * pb > lds_max / 2) pb >>= 1;
+    while (pb > 1 && zcol * pb > lds_max / 8) pb >>= 1;                     // small blocks, many per CU: their load / transform / store phases overlap (512^3: pb 8 -> 2, 1.27 -> 1.12 ms)
+    if (getenv("KSFD_SPEC_PB")) pb = std::max(1, std::min(pb, atoi(getenv("KSFD_SPEC_PB"))));        // experiment knob
     if (zcol * pb > lds_max) return;
     S.pb = pb;
     S.lds_z3 = zcol * pb;
@@ -343,7 +349,8 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         const int cz = 1 << S.lg_cz;
         const long long nzg = h->cfg.n[2], nzl = G.sloc;
         const int thr_y = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.npair * cz * G.ny / 16));
-        const int thr_z = (int)std::min<long long>(1024, std::max<long long>(256, (long long)2 * S.npair * S.pb * nzg / 16));
+        int thr_z = (int)std::min<long long>(1024, std::max<long long>(128, (long long)2 * S.npair * S.pb * nzg / 16));
+        if (getenv("KSFD_SPEC_THRZ")) thr_z = atoi(getenv("KSFD_SPEC_THRZ"));
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
             hipLaunchKernelGGL(k_spec3_y_fwd, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)nzl, S.lg_cz, S.npair, S.lg_rb3,
