@@ -446,7 +446,8 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
     double *r = h->Z;                              // residual (the fused-stage path leaves Z unused)
     float *r32 = reinterpret_cast<float *>(h->Z);  // ... kept in fp32 while only the preconditioner reads it
     double rn = bn, rprev = bn;
-    const bool fused = fused_ok(h);
+    // fp32 residual with the norm from the store epilogue: the 2-D strip kernel, or the 3-D one when its wave count fits the partial buffer
+    const bool fused = fused_ok(h) || (strip3d_ok(h) && (long long)make_k3d(h).nblocks * (KSFD_BLOCK / KSFD_WAVE) <= part_capacity());
     bool slow = false;
     for (int k = 0; k < maxit; k++) {
         if (k == 0) rc = spec_apply(h, shift, b, x, nullptr, nullptr, guess);

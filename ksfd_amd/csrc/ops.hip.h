@@ -336,6 +336,24 @@ static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const T
 // fp64 from the store epilogue -> h->hres[0].  Single rank, strip kernels.
 static int op_residual32(ksfd_handle *h, const double *x, double shift, const double *b, float *r32)
 {
+    if (h->G.dim == 3) {
+        // 3-D strip kernel: dG plane, then the z-marching Jacobian action in residual mode with fp32 output and the norm in its epilogue
+        const KGeom &G = h->G;
+        int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+        {
+            Scope sc(h, KC_GFIELD, 8.0 * (2 + h->P.nlig + G.F) * (double)G.plane);
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, x, h->dGb));
+        }
+        K3D K = make_k3d(h);
+        const long long nwaves = (long long)K.nblocks * (KSFD_BLOCK / KSFD_WAVE);
+        if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");
+        {
+            Scope sc(h, KC_JVP, (8.0 * (2.0 * G.F + 3) + 4.0 * G.F) * (double)G.nloc, 8.0 * 4.0 * G.F * (double)G.nloc);
+            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, x, (const double *)h->dGb, 2, shift, r32, b, 0.0, 0.0, h->part));
+        }
+        HIPCHK(h, hipGetLastError());
+        return reduce_rows(h, 1, (int)nwaves, 0);
+    }
     KStrips K = make_strips(h, true);
     const long long nwaves = (long long)K.nstrips * K.nseg;
     if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");

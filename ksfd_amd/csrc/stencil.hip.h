@@ -1046,13 +1046,18 @@ __device__ __forceinline__ long long ksfd_planeoff(const KGeom &G, long long k)
     return (k + G.ng) * pl;
 }
 
-template <int NL>
+// TO: storage type of `out` (float for the residual of the spectral defect correction, which only the preconditioner reads);
+// normpart != NULL: sum of squares of everything this wave stored -> normpart[blockIdx.x * 4 + wave] (fixed-order second stage)
+template <int NL, typename TO = double>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K3D S, const double *__restrict__ C,
                                                              const double *__restrict__ v, const double *__restrict__ dG,
-                                                             int mode, double shift, double *__restrict__ out,
-                                                             const double *__restrict__ yadd = nullptr, double alpha = 0.0, double beta = 0.0)
+                                                             int mode, double shift, TO *__restrict__ out,
+                                                             const double *__restrict__ yadd = nullptr, double alpha = 0.0, double beta = 0.0,
+                                                             double *__restrict__ normpart = nullptr)
 {
     const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x >> 6;
+    if (normpart && lane == 0) normpart[(long long)blockIdx.x * (KSFD_BLOCK / KSFD_WAVE) + wv] = 0.0;      // waves that leave early contribute nothing
+    double nacc = 0.0;
     const long long bid = ksfd_xcd_remap(blockIdx.x, S.nblocks);
     const long long nb_valid = (long long)S.nstrips * S.nygrp * S.nzseg;
     if (bid >= nb_valid) return;
@@ -1185,9 +1190,15 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
                     const double2 yy = yv_add[c];
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
-                ksfd_st2(out + (long long)c * G.plane + o, a, b);
+                if constexpr (sizeof(TO) == 4) *reinterpret_cast<float2 *>(out + (long long)c * G.plane + o) = make_float2((float)a, (float)b);
+                else ksfd_st2(out + (long long)c * G.plane + o, a, b);
+                nacc += a * a + b * b;
             }
         }
+    }
+    if (normpart) {
+        nacc = ksfd_wave_sum(nacc);
+        if (lane == 0) normpart[(long long)blockIdx.x * (KSFD_BLOCK / KSFD_WAVE) + wv] = nacc;
     }
 }
 
