@@ -515,12 +515,15 @@ __device__ __forceinline__ void kspec_cols_symbol(const KFFTPlan &PY, kcf *lds, 
     case 7: { constexpr int NL = 7; CALL; } break; case 8: { constexpr int NL = 8; CALL; } break; case 9: { constexpr int NL = 9; CALL; } break; \
     case 10: { constexpr int NL = 10; CALL; } break; case 11: { constexpr int NL = 11; CALL; } break; default: { constexpr int NL = 12; CALL; } break; }
 
+// NPAIR_T: number of field pairs at compile time for the common cases (1: one ligand, 2: two or three), 0 = run-time value.  With the
+// sequence count known the loops around the transforms simplify: 134 us against 145 us for the run-time version at 4096^2, F = 2.
+template <int NPAIR_T>
 __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ Wt, int lg_rb, const kcf *__restrict__ tw,
                                                    const int4 *__restrict__ pairtab, const int *__restrict__ posy, const int *__restrict__ kyofpos,
                                                    const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
-    const int npair = (S.nlig + 2) / 2;
+    const int npair = NPAIR_T ? NPAIR_T : (S.nlig + 2) / 2;
     const int ny = PY.n;
     const int4 pt = pairtab[kspec_tile(blockIdx.x, gridDim.x)];       // consecutive pairs (= neighbouring positions) on one XCD
     const bool self = pt.w != 0;                                // kx = 0 and kx = nx/2 are their own partners
@@ -570,7 +573,11 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     __syncthreads();
     kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
     }
-    KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol<NL>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S)));
+    if (NPAIR_T == 1) kspec_cols_symbol<1>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S);
+    else if (NPAIR_T == 2) {
+        if (S.nlig == 2) kspec_cols_symbol<2>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S);
+        else kspec_cols_symbol<3>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S);
+    } else { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol<NL>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S))); }
     __syncthreads();
     if (r16 && (PY.flags & 2)) {
         kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw, 1);
@@ -789,12 +796,13 @@ __device__ __forceinline__ void kspec3_z_symbol(const KFFTPlan &PZ, kcf *kspec_l
 // pairtab[e] = (column A, column B, kx | ky << 16, self) with column = pos_x * ny + pos_y; self: A == B is its own partner
 // Column storage as in k_spec_cols: a column consists of nz >> lg_pl pieces of 2^lg_pl elements, `pstride` elements apart (one piece
 // per z-slab rank after the all-to-all; a single piece on one rank).
+template <int NPAIR_T>      // as k_spec_cols: 1, 2 or 0 = run-time number of field pairs
 __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb, long long ncol, int lg_pl, long long pstride, kcf *__restrict__ W2, const kcf *__restrict__ tw,
                                                   const int4 *__restrict__ pairtab, const int *__restrict__ posz, const int *__restrict__ kzofpos,
                                                   const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
-    const int npair = (S.nlig + 2) / 2;
+    const int npair = NPAIR_T ? NPAIR_T : (S.nlig + 2) / 2;
     const int nz = PZ.n;
     const int sstride = nz + (nz >> 4) + 1;
     const int e0 = blockIdx.x * pb;
@@ -819,7 +827,11 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
     });
     __syncthreads();
     kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw);
-    KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S)));
+    if (NPAIR_T == 1) kspec3_z_symbol<1>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S);
+    else if (NPAIR_T == 2) {
+        if (S.nlig == 2) kspec3_z_symbol<2>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S);
+        else kspec3_z_symbol<3>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S);
+    } else { KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S))); }
     __syncthreads();
     kspec_fft_inv(PZ, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {

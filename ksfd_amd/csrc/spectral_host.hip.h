@@ -114,7 +114,9 @@ static void spec_build3d(ksfd_handle *h)
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_y_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_y3);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_y_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_y3);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_spec3_z, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3);
+        if (e == hipSuccess) e = S.npair == 1 ? hipFuncSetAttribute((const void *)k_spec3_z<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3)
+                               : S.npair == 2 ? hipFuncSetAttribute((const void *)k_spec3_z<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3)
+                                              : hipFuncSetAttribute((const void *)k_spec3_z<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_z3);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
     // ownership of the x positions (as in 2-D): top digit -> (rank, index of the digit in that rank's list)
@@ -206,7 +208,9 @@ static void spec_build(ksfd_handle *h)
     {
         hipError_t e = hipSuccess;
         e = S.cols_split ? hipFuncSetAttribute((const void *)k_spec_cols_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols)
-                         : hipFuncSetAttribute((const void *)k_spec_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols);
+                         : S.npair == 1 ? hipFuncSetAttribute((const void *)k_spec_cols<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols)
+                         : S.npair == 2 ? hipFuncSetAttribute((const void *)k_spec_cols<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols)
+                                        : hipFuncSetAttribute((const void *)k_spec_cols<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
     auto twiddles = [](int n) {
@@ -365,8 +369,10 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
             const long long pstride = (long long)S.npair * S.nxl * G.ny << S.lg_pl;
-            hipLaunchKernelGGL(k_spec3_z, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)S.nxl * G.ny, S.lg_pl, pstride, Wz,
-                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y);
+#define KSPEC_Z_LAUNCH(NP) hipLaunchKernelGGL(k_spec3_z<NP>, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)S.nxl * G.ny, S.lg_pl, pstride, Wz, \
+                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y)
+            if (S.npair == 1) KSPEC_Z_LAUNCH(1); else if (S.npair == 2) KSPEC_Z_LAUNCH(2); else KSPEC_Z_LAUNCH(0);
+#undef KSPEC_Z_LAUNCH
         }
         if (h->size > 1) {
             Scope sc(h, KC_HALO, pn);
@@ -397,9 +403,13 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
                 hipLaunchKernelGGL(k_spec_cols_split, dim3((unsigned)S.nblk_cols, (unsigned)S.npair), dim3(thr_cols), S.lds_cols, h->st, phase, py_c, S.nxl, S.lg_pl, pstride, spec,
                                    (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, res, (const kcf *)S.twy,
                                    (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
-        } else
-        hipLaunchKernelGGL(k_spec_cols, dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy,
-                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
+        } else {
+#define KSPEC_COLS_LAUNCH(NP) hipLaunchKernelGGL(k_spec_cols<NP>, dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, \
+                           (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy, \
+                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y)
+            if (S.npair == 1) KSPEC_COLS_LAUNCH(1); else if (S.npair == 2) KSPEC_COLS_LAUNCH(2); else KSPEC_COLS_LAUNCH(0);
+#undef KSPEC_COLS_LAUNCH
+        }
     }
     if (h->size > 1) {
         Scope sc(h, KC_HALO, pn);
