@@ -200,16 +200,27 @@ static int op_jvp(ksfd_handle *h, const double *u, const double *v, int mode, do
 }
 
 // Once per step: C = [rho, G, G_rho, G_U..] of the (ghost-filled) state u
-static int op_jcoef(ksfd_handle *h, const double *u)
+// want_means: the grid means of the spectral preconditioner come out of the same launch (resident state only)
+static int op_jcoef(ksfd_handle *h, const double *u, bool want_means = false)
 {
     const KGeom &G = h->G;
     int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     if (!h->coef32 && h->poly_fp32 && fused_ok(h) && h->P.nlig <= 4 && G.plane % 2 == 0 && G.inner % 2 == 0 &&
         hipMalloc((void **)&h->coef32, sizeof(float) * (size_t)(3 + h->P.nlig) * G.plane) != hipSuccess) { h->coef32 = nullptr; h->poly_fp32 = false; }
     float *c32 = h->poly_fp32 ? h->coef32 : nullptr;
+    want_means = want_means && (long long)(1 + h->P.nlig) * nbp <= part_capacity();
+    {
     Scope sc(h, KC_GFIELD, (8.0 * (G.F + 3 + h->P.nlig) + (c32 ? 4.0 * (3 + h->P.nlig) : 0.0)) * (double)G.plane);
-    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef, c32));
+    NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_jcoef<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, h->P, u, h->coef, c32, want_means ? h->part : (double *)nullptr));
+    }
     HIPCHK(h, hipGetLastError());
+    if (want_means) {
+        int rc = reduce_rows(h, 1 + h->P.nlig, nbp, 0);
+        if (rc) return rc;
+        const double ntot = (double)h->cfg.n[0] * (double)h->cfg.n[1] * (double)h->cfg.n[2];
+        h->spec.a_rr = h->hres[0] / ntot;
+        for (int l = 0; l < h->P.nlig; l++) h->spec.a_rU[l] = h->hres[1 + l] / ntot;
+    }
     return KSFD_OK;
 }
 
@@ -221,10 +232,10 @@ static int ensure_coef(ksfd_handle *h, bool ghosts_done = false)
     if (h->coef_fresh) return KSFD_OK;
     int rc;
     if (!ghosts_done && (rc = halo(h, h->u))) return rc;
-    if ((rc = op_jcoef(h, h->u))) return rc;
+    if ((rc = op_jcoef(h, h->u, h->spec.ok))) return rc;
     h->coef_fresh = true;
     h->mg_coef_valid = false; h->mg_shift = -1.0;
-    h->spec.means_valid = false;
+    h->spec.means_valid = h->spec.ok && (long long)(1 + h->P.nlig) * std::min<long long>((h->G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096) <= part_capacity();
     return KSFD_OK;
 }
 

@@ -801,10 +801,16 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_velmax3d(KGeom G, KPhys P, int z
 // Traffic per point: (3+NL) + (1+NL) reads + (1+NL) writes  (F=2: 64 B).
 // ---------------------------------------------------------------------------------------------
 template <int NL>
+// meanpart != NULL: per-block partial sums of rho*G_rho and rho*G_Ul over the OWNED points (the grid means the spectral preconditioner
+// is built from: no pass of its own over the planes just written)
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jcoef(KGeom G, KPhys P, const double *__restrict__ u,
-                                                      double *__restrict__ C, float *__restrict__ C32 = nullptr)
+                                                      double *__restrict__ C, float *__restrict__ C32 = nullptr, double *__restrict__ meanpart = nullptr)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long own0 = (long long)G.ng * G.inner, own1 = own0 + G.nloc;
+    double macc[NL + 1];
+#pragma unroll
+    for (int i = 0; i <= NL; i++) macc[i] = 0.0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < G.plane; e += stride) {
         double rho = ksfd_clamp(u[e], P.rhomin);
         double U[NL], GU[NL];
@@ -823,6 +829,26 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jcoef(KGeom G, KPhys P, const do
             C32[2 * G.plane + e] = (float)gr;
 #pragma unroll
             for (int l = 0; l < NL; l++) C32[(long long)(3 + l) * G.plane + e] = (float)GU[l];
+        }
+        if (meanpart && e >= own0 && e < own1) {
+            macc[0] += rho * gr;
+#pragma unroll
+            for (int l = 0; l < NL; l++) macc[l + 1] += rho * GU[l];
+        }
+    }
+    if (meanpart) {
+        __shared__ double red[KSFD_BLOCK / KSFD_WAVE][NL + 1];
+        const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x / KSFD_WAVE;
+#pragma unroll
+        for (int i = 0; i <= NL; i++) {
+            const double t = ksfd_wave_sum(macc[i]);
+            if (lane == 0) red[wv][i] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x <= NL) {
+            double t = 0.0;
+            for (int q = 0; q < KSFD_BLOCK / KSFD_WAVE; q++) t += red[q][threadIdx.x];
+            meanpart[(long long)threadIdx.x * gridDim.x + blockIdx.x] = t;
         }
     }
 }
