@@ -619,8 +619,12 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     const int max_rej = opts->max_reject < 0 ? 0x7fffffff : opts->max_reject;      // PETSc: -ts_max_reject -1 = unlimited
     const bool single = (opts->reserved & 2) != 0;                                   // one attempt per call (the caller owns the reject loop)
     // KSFDTS.solve grooms the global vector before every TS.step (KSFD/ksfdts.py:210)
-    if ((rc = ksfd_groom(h))) goto out;
-    if ((rc = op_copy(h, h->usave, h->u))) goto out;
+    {
+        // groom + roll-back copy of the owned points in one pass (ghost units of usave are never used: every roll-back is followed by a halo exchange)
+        Scope sc(h, KC_MISC, vbytes(h, 3));
+        hipLaunchKernelGGL(k_groom, vgrid(h), dim3(KSFD_BLOCK), 0, h->st, h->kv, h->u, h->P.rhomin, h->P.Umin, h->usave);
+        if (hipGetLastError() != hipSuccess) { rc = fail(h, KSFD_EHIP, "k_groom launch failed"); goto out; }
+    }
     if ((rc = halo(h, h->u))) goto out;
     if (h->use_frozen && (rc = ensure_coef(h, true))) goto out;      // usually already there: the CFL check after the last step made them
     h->poly_shift = -1.0;

@@ -438,13 +438,17 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rosw_finish(KVec g, double *__re
 }
 
 // KSFDTS.groom on the stored state (KSFD/ksfdts.py:231-237)
-__global__ void __launch_bounds__(KSFD_BLOCK) k_groom(KVec g, double *__restrict__ u, double rhomin, double Umin)
+// copy != NULL: the groomed owned points are stored there as well (the step's roll-back copy: no pass of its own)
+__global__ void __launch_bounds__(KSFD_BLOCK) k_groom(KVec g, double *__restrict__ u, double rhomin, double Umin, double *__restrict__ copy = nullptr)
 {
     const long long base = (long long)blockIdx.y * g.plane + g.off;
     const double lo = blockIdx.y == 0 ? rhomin : Umin;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride)
-        u[base + p] = ksfd_clamp(u[base + p], lo);
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.nloc; p += stride) {
+        const double v = ksfd_clamp(u[base + p], lo);
+        u[base + p] = v;
+        if (copy) copy[base + p] = v;
+    }
 }
 
 // sum of plane 0 (count_worms, KSFD/ksfdts.py:239-246)
