@@ -453,7 +453,8 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
         if (k == 0) rc = spec_apply(h, shift, b, x, nullptr, nullptr, guess);
         else rc = fused ? spec_apply(h, shift, nullptr, x, x, r32) : spec_apply(h, shift, r, x, x);
         if (rc) return rc;
-        if (h->size > 1 && (rc = halo(h, x))) return rc;                                     // the spectral application wrote owned rows only
+        // the spectral application wrote owned rows only; the 2-D fused residual exchanges the ghost rows itself, behind its interior rows
+        if (h->size > 1 && !(fused && h->G.dim == 2) && (rc = halo(h, x))) return rc;
         if (fused) {
             if ((rc = op_residual32(h, x, shift, b, r32))) return rc;                          // r = b - A x (fp32 copy), ||r||^2 -> hres[0]
         } else {

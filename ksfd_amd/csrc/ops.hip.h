@@ -343,6 +343,9 @@ static int jvp2d_launch_t(ksfd_handle *h, const KStrips &K, double frac, const T
     return KSFD_OK;
 }
 
+template <typename TC, typename TV, typename TY, typename TO>
+static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shift, TO *out, const TY *yadd, double alpha, double beta, double *normpart = nullptr);
+
 // r32 = b - A x stored in fp32 (its only reader is the spectral preconditioner, which works in fp32 anyway) with ||r||^2 in
 // fp64 from the store epilogue -> h->hres[0].  Single rank, strip kernels.
 static int op_residual32(ksfd_handle *h, const double *x, double shift, const double *b, float *r32)
@@ -368,17 +371,20 @@ static int op_residual32(ksfd_handle *h, const double *x, double shift, const do
     KStrips K = make_strips(h, true);
     const long long nwaves = (long long)K.nstrips * K.nseg;
     if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");
-    int rc = jvp2d_launch_t<double, double, double, float>(h, K, 1.0, (const double *)h->coef, x, 2, shift, r32, b, 0.0, 0.0, h->part);
+    // slab ranks: the ghost rows of x travel while the interior segments are computed (the caller has NOT exchanged them)
+    int rc = h->size > 1 ? jvp2d_halo_t<double, double, double, float>(h, (const double *)h->coef, const_cast<double *>(x), 2, shift, r32, b, 0.0, 0.0, h->part)
+                         : jvp2d_launch_t<double, double, double, float>(h, K, 1.0, (const double *)h->coef, x, 2, shift, r32, b, 0.0, 0.0, h->part);
     if (rc) return rc;
     return reduce_rows(h, 1, (int)nwaves, 0);
 }
 
 template <typename TC, typename TV, typename TY, typename TO>
-static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shift, TO *out, const TY *yadd, double alpha, double beta)
+// normpart != NULL: per-wave partials of ||out||^2, numbered over ALL segments (interior launch first, then the two boundary segments)
+static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shift, TO *out, const TY *yadd, double alpha, double beta, double *normpart)
 {
     const KGeom &G = h->G;
     KStrips K = make_strips(h, true);
-    if (h->size == 1) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
+    if (h->size == 1) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta, normpart);
     const long long scale = sizeof(double) / sizeof(TV);            // 1 for double, 2 for float
     const bool ovl = h->overlap && K.nseg >= 3;
     int rc;
@@ -388,7 +394,7 @@ static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shi
         Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = K.nseg - 2;
         long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
         Ki.nblocks = (int)((nb + 7) / 8 * 8);
-        if ((rc = jvp2d_launch_t(h, Ki, (double)Ki.nseg / K.nseg, C, v, mode, shift, out, yadd, alpha, beta))) return rc;
+        if ((rc = jvp2d_launch_t(h, Ki, (double)Ki.nseg / K.nseg, C, v, mode, shift, out, yadd, alpha, beta, normpart))) return rc;
         HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
     }
     {
@@ -396,14 +402,14 @@ static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shi
         if (h->tr->exchange(reinterpret_cast<double *>(v), G.F, G.plane / scale, G.inner / scale, G.sloc, G.ng, ovl ? h->st_comm : h->st))
             return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
     }
-    if (!ovl) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta);
+    if (!ovl) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta, normpart);
     HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
     HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
     KStrips Kb = K;
     Kb.seg0 = 0; Kb.seg_stride = K.nseg - 1; Kb.nseg = 2;
     long long nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
     Kb.nblocks = (int)((nb + 7) / 8 * 8);
-    return jvp2d_launch_t(h, Kb, 2.0 / K.nseg, C, v, mode, shift, out, yadd, alpha, beta);
+    return jvp2d_launch_t(h, Kb, 2.0 / K.nseg, C, v, mode, shift, out, yadd, alpha, beta, normpart ? normpart + (long long)K.nstrips * (K.nseg - 2) : nullptr);
 }
 
 // VW = 2 when every plane/offset/length is even (all accesses 16-byte aligned double2)
