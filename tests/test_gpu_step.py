@@ -300,6 +300,39 @@ def test_stage_guesses_in_the_multigrid_regime_save_iterations_same_answer():
     k.close()
 
 
+@pytest.mark.parametrize('shape,nlig', [((64, 64), 1), ((40, 24), 2), ((32, 32, 32), 1)])
+def test_checkpoint_restore_replays_the_same_steps(shape, nlig):
+    """ksfd_checkpoint (what bench.py walks its pinned window with): state, and what the solvers remember from step to step, come back
+    exactly -- the steps after a restore are bitwise the steps after the save (spectral, polynomial and plain regimes on the way)"""
+    dim = len(shape)
+    cfg = ProblemConfig.standard(dim, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=nlig)
+    rng = np.random.default_rng(31)
+    rho = 9000 + 90 * rng.standard_normal(cfg.N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(nlig)])
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
+    t, h = 0.0, 1e-3
+    for _ in range(4):
+        t, h, st, rc = k.step(t, h, opts)
+    k.checkpoint()
+    tc, hc = t, h
+
+    def run():
+        tt, hh, out = tc, hc, []
+        for _ in range(5):
+            tt, hh, st, rc = k.step(tt, hh, opts)
+            out.append((tt, hh, st.linear_its, st.rejections, st.pc_used, k.get_state().copy()))
+        return out
+    first = run()
+    k.restore()
+    second = run()
+    for a, b in zip(first, second):
+        assert a[:5] == b[:5]
+        assert np.array_equal(a[5], b[5])
+    k.close()
+
+
 @pytest.mark.parametrize('restart', [5, 9])
 def test_short_restart_lengths_give_the_same_step(restart):
     """large grids run with a restart length sized to the free HBM (ksfd_create); restarts + recycling with few slots must
