@@ -5,8 +5,9 @@
   (N > 1 without a launcher: this script starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
    --master-addr 127.0.0.1 ... bench.py ...` itself, before anything touches the GPU, and relays rank 0's line)
 
-A "step" is one implicit time step (KSFDTS.solve loop body, KSFD/ksfdts.py:207-228: groom -> 4-stage ROSW RA34PW2 step
-with matrix-free preconditioned GMRES -> CFL velocity check) of the BASELINE.json headline config: 2-D 4096^2, one
+A "step" is one implicit time step (KSFDTS.solve loop body, KSFD/ksfdts.py:207-228: groom -> 4-stage ROSW RA34PW2 step,
+every stage system solved matrix-free on the device (which solver ran is reported per step) -> CFL velocity check) of the
+BASELINE.json headline config: 2-D 4096^2, one
 ligand, fp64, options84 physics/spacing, synthetic random-perturbation initial data, state resident in
 HBM.  The SAME global grid is slab-decomposed over the N GPUs (strong scaling).
 
@@ -21,10 +22,15 @@ over a run, and a step at h = 1 costs several times a step at h = 1e-3):
       window is the same work, so any K that is a multiple of the window gives the same number; W warm-up steps walk the
       same window first.  value = N_grid * K / wall.
   `fixed_h`: 100 steps at h = 1e-3 from the start values (SURVEY.md 8d's second run), its own rate.
+  `aggregated`: the late phase of a production run, where the wall clock of a long run goes (aggregates have formed, the
+      constant-coefficient inverse no longer contracts, the multigrid-preconditioned GMRES takes over): a 256^2 run with
+      options81 spacing from dt0 to the aggregated state, tiled periodically to 2048^2 (an exact solution of the larger
+      problem), then a few adaptive steps timed there.  Its own rate, never part of `value`.
 
 One JSON line on rank 0, with `roofline` for the dominant kernel class of the timed region (HIP events on the library's
-compute stream) and `cpu_baseline` (the oracle's restatement of the same step, timed on the host cores on a bounded
-sample).
+compute stream), `cpu_baseline` (the oracle's restatement of the same step with unpreconditioned GMRES, OpenMP over the host
+cores, bounded sample) and `cpu_baseline_lu` (the REFERENCE's algorithm -- assembled Jacobian, one sparse LU per step, four
+back-substitutions, options84:58-60 -- from the oracle's operators + scipy's SuperLU on a bounded sample).
 """
 import argparse
 import json
@@ -62,6 +68,10 @@ def parse_args(argv=None):
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-n', type=int, default=1024)
+    ap.add_argument('--cpu-lu-n', type=int, default=256, help='grid of the sparse-LU CPU baseline (0 skips it); SuperLU needs ~15 s at 256^2, > 80 s at 512^2')
+    ap.add_argument('--agg-tile', type=int, default=256, help='grid of the run that produces the aggregated state (0 skips the leg)')
+    ap.add_argument('--agg-n', type=int, default=2048, help='grid the aggregated state is tiled to')
+    ap.add_argument('--agg-steps', type=int, default=5)
     ap.add_argument('--yseg', type=int, default=0)
     return ap.parse_args(argv)
 
@@ -89,6 +99,17 @@ def build_problem(n, nlig, spacing_ref=4.0 / 1536, dim=2):
 
 
 PC_NAMES = {1: 'none', 2: 'multigrid', 4: 'polynomial', 8: 'spectral'}
+SOLVER_TEXT = {
+    'spectral': 'defect correction x += M^-1 (b - A x), M = constant-coefficient part of shift*I - J inverted by hand-written LDS FFTs; '
+                'no Krylov vectors; stops on the true fp64 residual (last sweep of a solve applied on the measured contraction)',
+    'none': 'unpreconditioned restarted GMRES(30)',
+    'polynomial': 'flexible GMRES(30) with a Chebyshev polynomial preconditioner (degree <= 6)',
+    'multigrid': 'GMRES(30) right-preconditioned with one geometric-multigrid V(2,2) cycle',
+}
+MIXED_PRECISION = ('fp64: state, stage vectors, right-hand sides, Jacobian action, residual norm and stopping test, step completion and '
+                   'error norm; fp32: the FFT work array and arithmetic of M^-1 (spectral solver), the STORED residual that only M^-1 reads '
+                   '(its norm is accumulated from the fp64 values before rounding), coefficient copy + Horner temporaries inside the '
+                   'polynomial preconditioner, block-diagonal inverses of the multigrid smoother')
 
 
 def main():
@@ -165,13 +186,17 @@ def main():
 
     class Tally:
         def __init__(self):
-            self.steps = self.its = self.rej = 0
+            self.steps = self.its = self.rej = self.launches = self.syncs = self.resid = self.pred = 0
             self.hs, self.pcs, self.bytes = [], {}, 0.0
 
         def add(self, st):
             self.steps += 1
             self.its += st.linear_its
             self.rej += st.rejections
+            self.launches += st.launches
+            self.syncs += st.host_syncs
+            self.resid += st.residual_evals
+            self.pred += st.predicted_final
             self.hs.append(st.h_used)
             self.bytes += st.bytes
             for bit, nm in PC_NAMES.items():
@@ -179,9 +204,12 @@ def main():
                     self.pcs[nm] = self.pcs.get(nm, 0) + 1
 
         def summary(self):
-            return {'steps': self.steps, 'gmres_its_per_step': self.its / max(self.steps, 1), 'rejections': self.rej,
+            n = max(self.steps, 1)
+            # linear_its: applications of the spectral inverse (sweeps) where the spectral solver ran, GMRES iterations elsewhere
+            return {'steps': self.steps, 'linear_its_per_step': self.its / n, 'rejections': self.rej,
                     'h_min': float(np.min(self.hs)), 'h_max': float(np.max(self.hs)), 'h_mean': float(np.mean(self.hs)),
-                    'steps_by_preconditioner': self.pcs}
+                    'steps_by_solver': self.pcs, 'residual_evals_per_step': self.resid / n, 'predicted_final_sweeps_per_step': self.pred / n,
+                    'launches_per_step': self.launches / n, 'host_syncs_per_step': self.syncs / n}
 
     # ---------------- fixed-h leg: 100 steps at h = 1e-3 from the start values
     fixed = None
@@ -200,8 +228,8 @@ def main():
         barrier()
         el = max_over_ranks(time.perf_counter() - t0)
         fixed = {'h': args.fixed_h, 'steps': args.fixed_steps, 'ms_per_step': 1e3 * el / args.fixed_steps,
-                 'value': cfg.N * args.fixed_steps / el, 'gmres_its_per_step': tal.its / args.fixed_steps,
-                 'steps_by_preconditioner': tal.pcs}
+                 'value': cfg.N * args.fixed_steps / el, 'linear_its_per_step': tal.its / args.fixed_steps,
+                 'steps_by_solver': tal.pcs}
 
     # ---------------- ramp from dt0 to t* (setup of the pinned window; reported, not the headline)
     ks.set_state_random(zc, 9000.0)
@@ -254,6 +282,12 @@ def main():
     prof = ks.profile()
     ks.set_profiling(False)
 
+    aggregated = None
+    if world == 1 and args.dim == 2 and args.agg_tile > 0 and args.agg_steps > 0:
+        ks.close()                                            # its memory is not needed any more
+        ks = None
+        aggregated = aggregated_leg(args, klib, np)
+
     if rank == 0:
         N = cfg.N
         value = N * args.steps / elapsed
@@ -277,11 +311,15 @@ def main():
             'metric': 'grid-point-updates/sec (implicit step)', 'value': value, 'unit': 'grid-point-updates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': dict({'workload': '%dD %s %d-ligand Keller-Segel (options84 spacing/physics), implicit step = ROSW RA34PW2 + '
-                                        'matrix-free preconditioned GMRES(30) + CFL check; pinned window: the %d TSAdaptBasic '
-                                        '(rtol=1e-6, atol=0.01) steps that follow model time t*=%g of the run from dt0=%g, '
-                                        'walked cyclically' % (args.dim, 'x'.join([str(args.n)] * args.dim), args.nlig,
-                                                               args.window, args.t_star, args.dt0),
+            'config': dict({'workload': '%dD %s %d-ligand Keller-Segel (options84 spacing/physics), implicit step = 4-stage ROSW RA34PW2 '
+                                        '(frozen Jacobian, TSAdaptBasic) with matrix-free stage solves on the device [%s] + CFL check; '
+                                        'pinned window: the %d adaptive (rtol=1e-6, atol=0.01) steps that follow model time t*=%g of '
+                                        'the run from dt0=%g, walked cyclically' % (
+                                            args.dim, 'x'.join([str(args.n)] * args.dim), args.nlig,
+                                            ' | '.join('%s: %d of %d steps' % (k, v, tal.steps) for k, v in sorted(tal.pcs.items())),
+                                            args.window, args.t_star, args.dt0),
+                             'stage_solver': {k: SOLVER_TEXT[k] for k in sorted(tal.pcs)},
+                             'mixed_precision': MIXED_PRECISION,
                              'grid': [args.n] * args.dim, 'fields': cfg.F, 'ksp_rtol': float(o.ksp_rtol), 'pc_type': int(o.pc_type),
                              't_star': t_star, 'h_star': h_star, 'window': args.window, 't_end_of_window': t_last,
                              'parallelism': 'slab%d' % world, 'transport': getattr(ks, 'transport_name', 'none'),
@@ -296,18 +334,80 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'alg_bytes_per_launch': alg_bytes, 'impl_bytes_per_launch': impl_bytes, 'ms_per_launch': per_launch_ms,
                          'launches': int(d['launches']), 'rocprof_avg_us': rp_us, 'rocprof_source': rp_src,
+                         # whole step over the wall clock of the timed region: bytes the implementation moves, and SURVEY 8d's
+                         # algorithmic bytes of the same launches (every class)
                          'step_implementation_GBs': tal.bytes / elapsed / 1e9,
-                         'step_frac_of_peak': tal.bytes / elapsed / 1e9 / HBM_PEAK_GBS},
-            'ramp': ramp, 'fixed_h': fixed,
+                         'step_frac_of_peak': tal.bytes / elapsed / 1e9 / HBM_PEAK_GBS,
+                         'step_algorithmic_GBs': sum(v['alg_bytes'] for v in prof.values()) / elapsed / 1e9,
+                         'step_frac_algorithmic': sum(v['alg_bytes'] for v in prof.values()) / elapsed / 1e9 / HBM_PEAK_GBS},
+            'ramp': ramp, 'fixed_h': fixed, 'aggregated': aggregated,
             'kernels': kern, 'kernels_region': 'warmup steps (events on every launch)' if args.warmup > 0 else 'timed steps',
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, float(np.mean(tal.hs)))
+            if args.cpu_lu_n > 0 and args.dim == 2:
+                out['cpu_baseline_lu'] = cpu_baseline_lu(args, float(np.mean(tal.hs)))
         print(json.dumps(out), flush=True)
-    ks.close()
+    if ks is not None:
+        ks.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def aggregated_leg(args, klib, np):
+    """Late phase of a production run on one GPU (where DESIGN.md 2 says the wall clock of a long run goes).  A (tile)^2 run with
+    options81 spacing (width 1 at 384 points, options81:17) from the synthetic start values and dt0 = 1e-8 until aggregates have
+    formed (rho spread over more than a decade and the stepper has left the spectral regime), then that state tiled periodically to
+    (agg_n)^2 -- a periodic tiling is an exact solution of the larger problem -- and agg_steps adaptive steps timed there."""
+    from ksfd_amd.config import ProblemConfig
+    from ksfd_amd.initial import start_values
+    m, n = args.agg_tile, args.agg_n
+    reps = max(1, n // m)
+    n = m * reps
+    small = ProblemConfig.standard(2, (m, m), L=(m / 384.0,) * 2, nlig=args.nlig)
+    k1 = klib.KSFDHip(small)
+    k1.set_state(start_values(small))
+    opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)
+    t, h, nst = 0.0, 1e-8, 0
+    t0 = time.perf_counter()
+    mg_steps = 0
+    while nst < 600 and mg_steps < 60:                        # 60 steps into the regime the fallback solver owns
+        t, h, st, rc = k1.step(t, h, opts, raise_on_error=False)
+        nst += 1
+        if rc:
+            break
+        if st.pc_used & 2:
+            mg_steps += 1
+    setup_s = time.perf_counter() - t0
+    u = k1.get_state().reshape(small.F, m, m)
+    k1.close()
+    rho = u[0]
+    big = ProblemConfig.standard(2, (n, n), L=(n / 384.0,) * 2, nlig=args.nlig)
+    kb = klib.KSFDHip(big)
+    kb.set_state(np.tile(u, (1, reps, reps)).reshape(-1))
+    for _ in range(2):
+        t, h, st, rc = kb.step(t, h, opts)
+    kb.synchronize()
+    t0 = time.perf_counter()
+    its, pcs, hs, rej = 0, {}, [], 0
+    for _ in range(args.agg_steps):
+        t, h, st, rc = kb.step(t, h, opts)
+        kb.velocity_max()
+        its += st.linear_its
+        rej += st.rejections
+        hs.append(st.h_used)
+        for bit, nm in PC_NAMES.items():
+            if st.pc_used & bit:
+                pcs[nm] = pcs.get(nm, 0) + 1
+    kb.synchronize()
+    el = time.perf_counter() - t0
+    kb.close()
+    return {'grid': [n, n], 'fields': big.F, 'steps': args.agg_steps, 'ms_per_step': 1e3 * el / args.agg_steps,
+            'value': big.N * args.agg_steps / el, 'unit': 'grid-point-updates/s', 'linear_its_per_step': its / args.agg_steps,
+            'steps_by_solver': pcs, 'rejections': rej, 'h_mean': float(np.mean(hs)), 't': t,
+            'rho_min': float(rho.min()), 'rho_max': float(rho.max()),
+            'state': '%dx%d run (options81 spacing) from dt0=1e-8, %d steps in %.1f s to t=%.4g, tiled %dx%d' % (m, m, nst, setup_s, t, reps, reps)}
 
 
 def pmc_traffic(kernel_class):
@@ -380,6 +480,45 @@ def cpu_baseline(args, h):
     return {'value': cfg.N / dt, 'unit': 'grid-point-updates/s', 'cores': cores, 'kind': 'port',
             'sample': 'one ROSW+GMRES(30,CGS2, no preconditioner) step at h=%.4g on a %s sub-grid (same spacing/physics/IC '
                       'statistics), %s, %.1f s' % (h, 'x'.join([str(m)] * args.dim), note, dt)}
+
+
+
+
+def cpu_baseline_lu(args, h):
+    """The REFERENCE's algorithm for one step, on the CPU: Jacobian assembled entry by entry (the oracle's restatement of
+    Derivatives.Jacobian + ksfdMat.setValuesJacobian), shift*I - J factorised ONCE by a sparse direct solver, four back-substitutions
+    (-ksp_type preonly -pc_type lu, options84:58-60; PETSc hands the factorisation to MUMPS, here scipy's SuperLU with minimum-degree
+    ordering, one thread).  Bounded sample: SuperLU needs ~15 s for 256^2 x 2 unknowns and > 80 s for 512^2, so 256^2 it is."""
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from ksfd_amd.initial import start_values
+    from oracle import ko
+    m = args.cpu_lu_n
+    cfg = build_problem(m, args.nlig, dim=2)
+    u = start_values(cfg)
+    o = ko.Oracle(cfg)
+    At, Gi, bt, b2t, asum = ko.tableau()
+    gam = 1.0 / Gi[0, 0]
+    F, N = cfg.F, cfg.N
+    to_vec = lambda a: a.reshape(F, N).T.reshape(-1)
+    to_soa = lambda x: x.reshape(N, F).T.reshape(-1)
+    t0 = time.perf_counter()
+    ug = o.groom(u)
+    rp, col, val = o.jacobian_csr(ug)
+    J = sp.csr_matrix((val, col, rp), shape=(F * N, F * N))
+    lu = spla.splu((sp.identity(F * N, format='csc') / (gam * h) - J).tocsc(), permc_spec='MMD_AT_PLUS_A')
+    t_fact = time.perf_counter() - t0
+    Y = []
+    for i in range(4):
+        Z = ug + sum(At[i, j] * Y[j] for j in range(i))
+        Zdot = sum((Gi[i, j] / h) * Y[j] for j in range(i)) if i else 0.0
+        Y.append(to_soa(lu.solve(to_vec(o.rhs(Z) - Zdot))))
+    dt = time.perf_counter() - t0
+    return {'value': cfg.N / dt, 'unit': 'grid-point-updates/s', 'cores': 1, 'kind': 'port',
+            'sample': 'one ROSW step at h=%.4g on a %dx%d sub-grid (same spacing/physics/IC statistics): assembled Jacobian + one sparse LU '
+                      '(SuperLU, MMD ordering, %.1f s, fill %.3g nonzeros) + four back-substitutions, %.1f s in all'
+                      % (h, m, m, t_fact, lu.L.nnz + lu.U.nnz, dt)}
 
 
 if __name__ == '__main__':

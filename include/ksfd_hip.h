@@ -103,13 +103,16 @@ typedef struct ksfd_step_opts {
     int32_t reserved;           /* flags.  bit 0: classic two-pass CGS2 instead of CGS2 with the algebraic second projection;
                                  * bit 1: single attempt per call -- a rejected step returns with accepted = 0 and *hstep = the
                                  * controller's proposal (callers that must refresh stage-time data per attempt);
-                                 * bit 2: the previous attempt of this step was rejected (TSAdaptBasic then applies reject_safety) */
+                                 * bit 2: the previous attempt of this step was rejected (TSAdaptBasic then applies reject_safety);
+                                 * bit 3: the spectral defect correction verifies EVERY solve with a final residual evaluation (no
+                                 * predicted last sweep) */
 } ksfd_step_opts;
 
 typedef struct ksfd_step_stats {
     int32_t accepted;           /* 1 if the state advanced */
     int32_t rejections;
-    int32_t linear_its;         /* GMRES iterations over all stages and attempts */
+    int32_t linear_its;         /* linear iterations over all stages and attempts: GMRES iterations, or applications of the spectral
+                                 * inverse (sweeps of the defect correction) where pc_used has bit 8 */
     int32_t rhs_evals, jvp_evals;
     int32_t pc_used;            /* preconditioners the stage solves of this call ran with, OR of: 1 none, 2 multigrid V cycle,
                                  * 4 Chebyshev polynomial, 8 spectral (constant-coefficient FFT) */
@@ -117,6 +120,12 @@ typedef struct ksfd_step_stats {
     double h_used;              /* step actually taken (valid when accepted) */
     double ksp_resid;           /* last relative residual */
     double bytes;               /* algorithmic HBM bytes of all kernels launched by the call */
+    int32_t launches;           /* kernels / device copies the call enqueued on the compute stream */
+    int32_t host_syncs;         /* times the host waited for a device result inside the call (reduction hand-overs, stream
+                                 * synchronisations): the latency-bound part of a step on many slab ranks */
+    int32_t residual_evals;     /* true residuals b - A x evaluated by the spectral defect correction (one Jacobian action each) */
+    int32_t predicted_final;    /* stage solves whose LAST sweep was applied on the measured contraction of the earlier sweeps
+                                 * instead of a residual evaluation (ksp_rtol >= 1e-8 only; opts.reserved bit 3 switches it off) */
 } ksfd_step_stats;
 
 /* Per-kernel-class timing gathered with HIP events on the library's compute stream. */

@@ -49,6 +49,9 @@ struct SpecState {
     // adaptation: steps (counted by ksfd_step calls) before which the automatic choice leaves it alone after it converged badly
     long long bad_until = 0;
     int backoff = 8;
+    // largest contraction ||r_k+1|| / ||r_k|| of a defect-correction sweep measured in the current / the previous step
+    // (spec_solve: predicted last sweep)
+    double rho_step = 0.0, rho_prev = 0.0;
 };
 
 struct ksfd_handle {
@@ -62,6 +65,8 @@ struct ksfd_handle {
     bool Pst_valid[4] = { false, false, false, false };
     KVec kv;
     int rank = 0, size = 1, device = 0;
+    bool ring = false;               // ghost units + transport in use: size > 1, or ONE rank that is its own ring neighbour (ksfd_dist.size = 1 with a
+                                     // transport: the RCCL path executed end to end on a single GPU)
     int64_t slow0 = 0;               // first owned global slow index
     hipStream_t st = nullptr;
     hipStream_t st_comm = nullptr;            // halo exchange stream (overlapped with interior rows)
@@ -77,8 +82,12 @@ struct ksfd_handle {
     double *ckpt = nullptr;                 // ksfd_checkpoint slot (allocated on first save)
     double *bstore = nullptr;               // right-hand sides of stages 0..2 of the current step (initial guesses of the spectral solves)
     bool spec_guess = true;
+    bool spec_predict = true;               // predicted last sweep of the defect correction (spec_solve)
+    long long n_predicted = 0;              // ... how many solves ended that way
+    long long n_residual = 0;               // true residuals evaluated by the spectral defect correction
+    long long n_host_sync = 0;              // host waits on the device so far (reduction results, stream synchronisations)
     struct SolverMemo { double lamJ; int lam_age, lam_period; double mg_shift_floor; int sf_dir, sf_hold; bool sf_tried_down; double sf_prev_its, sf_prev_floor;
-                        long long nsteps, spec_bad_until; int spec_backoff; };
+                        long long nsteps, spec_bad_until; int spec_backoff; double spec_rho_step, spec_rho_prev; };
     SpecState spec;
     long long nsteps = 0;                   // ksfd_step calls so far
     double spec_from = 0.1;                 // stiffness above which pc_type 2 prefers the spectral solver (below: plain GMRES; measured at 4096^2, X = 0.19: 6 sweeps = 7.3 ms against 5 GMRES iterations = 7.9 ms per step)

@@ -83,13 +83,16 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     h->size = dist ? dist->size : 1;
     h->device = dist ? dist->device : 0;
     if (h->size < 1 || h->rank < 0 || h->rank >= h->size) { delete h; return fail(nullptr, KSFD_EINVAL, "bad rank/size"); }
+    // one rank WITH a transport = a ring of one: ghost units, halo exchange with itself, all-reduce over one rank, the own-piece path of
+    // the all-to-alls -- the whole multi-rank code path on a single GPU (how the RCCL transport is exercised on a one-GPU box)
+    h->ring = h->size > 1 || (dist && dist->transport != 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { delete h; return fail(nullptr, KSFD_EHIP, "no HIP device available (libksfd_hip has no CPU path)"); }
     if (h->device < 0 || h->device >= ndev) { delete h; return fail(nullptr, KSFD_EINVAL, "device %d of %d", h->device, ndev); }
 #define CFAIL(code, ...) do { int rc_ = fail(nullptr, code, __VA_ARGS__); ksfd_destroy(h); return rc_; } while (0)
     if (hipSetDevice(h->device) != hipSuccess) CFAIL(KSFD_EHIP, "hipSetDevice(%d) failed", h->device);
     if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) CFAIL(KSFD_EHIP, "hipStreamCreate failed");
-    if (h->size > 1 && (hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking) != hipSuccess ||
+    if (h->ring && (hipStreamCreateWithFlags(&h->st_comm, hipStreamNonBlocking) != hipSuccess ||
                         hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming) != hipSuccess)) CFAIL(KSFD_EHIP, "comm stream/event creation failed");
 
@@ -101,8 +104,8 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         CFAIL(KSFD_EINVAL, "slab axis extent %lld must be divisible by %d ranks with >= 4 units each", (long long)nglob, h->size);
     int64_t sloc = nglob / h->size;
     h->slow0 = sloc * h->rank;
-    G.ng = h->size > 1 ? 2 : 0;
-    G.wrap_slow = h->size == 1;
+    G.ng = h->ring ? 2 : 0;
+    G.wrap_slow = !h->ring;
     G.nx = cfg->n[0]; G.ny = cfg->dim >= 2 ? cfg->n[1] : 1; G.nz = cfg->dim >= 3 ? cfg->n[2] : 1;
     if (slow == 0) G.nx = sloc; else if (slow == 1) G.ny = sloc; else G.nz = sloc;
     G.inner = slow == 0 ? 1 : (slow == 1 ? G.nx : G.nx * G.ny);
@@ -128,7 +131,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         }
     }
     if (alloc_d(h, &h->dres, 128)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
-    if (h->size > 1) {
+    if (h->ring) {
         std::string terr;
         h->tr = make_transport(dist, G.F, G.inner, terr);
         if (!h->tr) CFAIL(KSFD_ECOMM, "transport %d: %s", dist->transport, terr.c_str());
@@ -180,7 +183,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     spec_build(h);                                            // leaves spec.ok = false where it does not apply (3-D, non power-of-two extents, ...)
     if (mg_build(h)) { mg_free(h); h->mg_ok = false; }        // out of memory for the hierarchy: run without the multigrid preconditioner
     if ((h->spec.ok || h->mg_ok) && alloc_d(h, &h->bstore, 3 * h->vlen)) { h->bstore = nullptr; h->spec_guess = false; h->err.clear(); }
-    if (h->size > 1) {
+    if (h->ring) {
         // which solvers exist decides the sequence of collectives of every step: all ranks must agree (an allocation that failed
         // on one rank only would otherwise leave the others waiting in an all-reduce)
         double flags[3] = { h->spec.ok ? 1.0 : 0.0, h->mg_ok ? 1.0 : 0.0, (h->spec_guess && h->bstore) ? 1.0 : 0.0 };
@@ -324,7 +327,7 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
         if (!h->ckpt && alloc_d(h, &h->ckpt, h->vlen)) return KSFD_ENOMEM;
         HIPCHK(h, hipMemcpyAsync(h->ckpt, h->u, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
         h->ckpt_memo = { h->lamJ, h->lam_age, h->lam_period, h->mg_shift_floor, h->sf_dir, h->sf_hold, h->sf_tried_down, h->sf_prev_its, h->sf_prev_floor,
-                         h->nsteps, h->spec.bad_until, h->spec.backoff };
+                         h->nsteps, h->spec.bad_until, h->spec.backoff, h->spec.rho_step, h->spec.rho_prev };
         h->ckpt_valid = true;
         return KSFD_OK;
     }
@@ -335,6 +338,7 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
     h->lamJ = m.lamJ; h->lam_age = m.lam_age; h->lam_period = m.lam_period; h->mg_shift_floor = m.mg_shift_floor;
     h->sf_dir = m.sf_dir; h->sf_hold = m.sf_hold; h->sf_tried_down = m.sf_tried_down; h->sf_prev_its = m.sf_prev_its; h->sf_prev_floor = m.sf_prev_floor;
     h->nsteps = m.nsteps; h->spec.bad_until = m.spec_bad_until; h->spec.backoff = m.spec_backoff; h->spec.means_valid = false;
+    h->spec.rho_step = m.spec_rho_step; h->spec.rho_prev = m.spec_rho_prev;
     h->mg_coef_valid = false; h->mg_shift = -1.0; h->poly_shift = -1.0; h->have_err = false;
     rec_reset(h);
     return KSFD_OK;
@@ -610,6 +614,9 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     memset(&st, 0, sizeof st);
     const double bytes0 = h->bytes_acc;
     const int64_t rhs0 = h->prof.launches[KC_RHS], jvp0 = h->prof.launches[KC_JVP];
+    int64_t launches0 = 0;
+    for (int c = 0; c < KSFD_NKCLASS; c++) launches0 += h->prof.launches[c];
+    const long long sync0 = h->n_host_sync, pred0 = h->n_predicted, resid0 = h->n_residual;
     int rc = KSFD_OK;
     const int64_t vs = h->vlen;
     double hh = *hstep;
@@ -629,6 +636,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
     if (h->use_frozen && (rc = ensure_coef(h, true))) goto out;      // usually already there: the CFL check after the last step made them
     h->poly_shift = -1.0;
     h->nsteps++;
+    if (h->spec.rho_step > 0.0) h->spec.rho_prev = h->spec.rho_step;      // contraction memory of the spectral sweeps: this step's maximum replaces the last one's
+    h->spec.rho_step = 0.0;
     while (true) {
         const double shift = 1.0 / (GAMMA_RA * hh);
         // stiffness estimate X = h*gamma*lambda_max of the diffusion part; the multigrid preconditioner pays off above ~60
@@ -668,7 +677,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         }
         const bool small = (double)h->G.F * (double)h->G.nloc <= 6.0e6;
         const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && !(opts->reserved & 1) && stiff >= 1e-3 &&
-                               (h->size == 1 || h->tr->device_allreduce()) &&
+                               (!h->ring || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
         const bool fuse_stage = (fused_ok(h) || (strip3d_ok(h) && h->rhs3d_strip)) && h->P.nlig <= 4 && h->fuse_stage;
         const int its_before = st.linear_its;
@@ -895,6 +904,14 @@ out:
     st.bytes = h->bytes_acc - bytes0;
     st.rhs_evals = (int32_t)(h->prof.launches[KC_RHS] - rhs0);
     st.jvp_evals = (int32_t)(h->prof.launches[KC_JVP] - jvp0);
+    {
+        int64_t l1 = 0;
+        for (int c = 0; c < KSFD_NKCLASS; c++) l1 += h->prof.launches[c];
+        st.launches = (int32_t)(l1 - launches0);
+    }
+    st.host_syncs = (int32_t)(h->n_host_sync - sync0);
+    st.predicted_final = (int32_t)(h->n_predicted - pred0);
+    st.residual_evals = (int32_t)(h->n_residual - resid0);
     if (stats) *stats = st;
     return rc;
 }
@@ -932,7 +949,7 @@ extern "C" int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_ma
     if (power_its > 0) h->mg_power_its = power_its;
     if (ratio > 1.0) h->mg_ratio = ratio;
     if (coarse_tol > 0.0) h->mg_coarse_tol = coarse_tol;
-    h->mg_use_graph = power_its != -7 && h->size == 1;     // power_its = -7: eager launches (debug / A-B timing); slab ranks: collectives inside the cycle
+    h->mg_use_graph = power_its != -7 && !h->ring;     // power_its = -7: eager launches (debug / A-B timing); slab ranks: collectives inside the cycle
     h->mg_shift = -1.0;
     return KSFD_OK;
 }

@@ -46,14 +46,14 @@ static int mg_build(ksfd_handle *h)
         h->mg.push_back(L);
         // next level: every rank keeps >= 4 slow units (ghost width 2 + the 4th-order star), global grid >= 8 per axis
         const long long rows_glob = rows * h->size;
-        if ((dim > 1 && ((nx % 2) || nx / 2 < 8)) || (rows % 2) || rows_glob / 2 < 8 || (h->size > 1 && rows / 2 < 4)) break;
+        if ((dim > 1 && ((nx % 2) || nx / 2 < 8)) || (rows % 2) || rows_glob / 2 < 8 || (h->ring && rows / 2 < 4)) break;
         if (dim == 3 && ((ny % 2) || ny / 2 < 8)) break;
         nx /= 2; rows /= 2;
         if (dim == 3) ny /= 2;
         for (int a = 0; a < 3; a++) { P.inv_h[a] *= 0.5; P.inv_h2[a] *= 0.25; }
     }
     h->mg_ok = h->mg.size() >= 2;
-    if (h->size > 1) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
+    if (h->ring) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
     return KSFD_OK;
 }
 
@@ -88,7 +88,7 @@ static void mg_launch_prolong(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, 
 // ghost rows of a level vector (np field planes) from the ring neighbours
 static int mg_halo(ksfd_handle *h, MGLevel &L, double *v, int np)
 {
-    if (h->size == 1) return KSFD_OK;
+    if (!h->ring) return KSFD_OK;
     Scope sc(h, KC_HALO, 4.0 * 8.0 * np * (double)L.G.inner * 2.0);
     if (h->tr->exchange(v, np, L.G.plane, L.G.inner, L.G.sloc, L.G.ng, h->st)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
     return KSFD_OK;
@@ -107,7 +107,7 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
                  const KSmooth *sm = nullptr)
 {
     const KGeom &G = L.G;
-    if (h->size > 1) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
+    if (h->ring) { int rch = mg_halo(h, L, const_cast<double *>(v), G.F); if (rch) return rch; }
     const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
     // planes moved: coefficients + v, plus per mode: 1/2: out (+ yadd); 5: yadd, Dinv, r, d; 6: Dinv, rr, x in and out
     const double by = 8.0 * ((3 + h->P.nlig) + G.F + (mode == 5 ? 3.0 * G.F + 0.5 * G.F * G.F : mode == 6 ? 3.0 * G.F + 0.5 * G.F * G.F : G.F + (mode == 2 ? G.F : 0))) * (double)G.nloc;

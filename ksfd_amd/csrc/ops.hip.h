@@ -5,7 +5,7 @@
 // ---- halo exchange (DMDA globalToLocal stand-in, KSFD/ksfdsym.py:919-920) -----------------------
 static int halo(ksfd_handle *h, double *vec)
 {
-    if (h->size == 1) return KSFD_OK;
+    if (!h->ring) return KSFD_OK;
     Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * h->G.F * (double)h->G.inner * 2.0);
     int rc = h->tr->exchange(vec, h->G.F, h->G.plane, h->G.inner, h->G.sloc, h->G.ng, h->st);
     if (rc) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
@@ -35,8 +35,9 @@ static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
 {
     // several ranks with a device-side all-reduce (RCCL): a one-block k_publish behind the all-reduce hands the result over
     // the same way; ksfd_amd.dist.open_handle checks that path end to end on a new handle and clears zero_copy if it fails
-    const bool zc = h->zero_copy && !h->capturing && rows <= 128 && (h->size == 1 || h->tr->device_allreduce());
-    const bool zc_here = zc && h->size == 1;
+    const bool zc = h->zero_copy && !h->capturing && rows <= 128 && (!h->ring || h->tr->device_allreduce());
+    const bool zc_here = zc && !h->ring;
+    h->n_host_sync++;
     const unsigned long long seq = zc ? ++h->pub_seq : 0;
     {
         Scope sc(h, KC_REDUCE, 8.0 * rows * (double)nblk);
@@ -44,7 +45,7 @@ static int reduce_rows(ksfd_handle *h, int rows, int nblk, int op)
         else hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(KSFD_BLOCK), 0, h->st, h->part, nblk, op, h->dres);
     }
     if (zc_here) { HIPCHK(h, hipGetLastError()); return spin_for(h, seq); }
-    if (h->size > 1) {
+    if (h->ring) {
         int rc = h->tr->allreduce(h->dres, rows, op, h->st);
         if (rc) return fail(h, KSFD_ECOMM, "allreduce failed: %s", h->tr->error().c_str());
         if (h->tr->result_on_host()) { memcpy(h->hres, h->tr->host_result(), sizeof(double) * rows); return KSFD_OK; }
@@ -290,7 +291,7 @@ static int op_jvp_frozen_halo(ksfd_handle *h, double *v, int mode, double shift,
 {
     int rc;
     const KGeom &G = h->G;
-    if (h->size == 1) return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
+    if (!h->ring) return op_jvp_frozen(h, v, mode, shift, out, yadd, alpha, beta);
     KStrips K = make_strips(h, true);
     if (!h->overlap || !fused_ok(h) || K.nseg < 3 || h->P.nlig > 4) {
         if ((rc = halo(h, v))) return rc;
@@ -372,7 +373,7 @@ static int op_residual32(ksfd_handle *h, const double *x, double shift, const do
     const long long nwaves = (long long)K.nstrips * K.nseg;
     if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");
     // slab ranks: the ghost rows of x travel while the interior segments are computed (the caller has NOT exchanged them)
-    int rc = h->size > 1 ? jvp2d_halo_t<double, double, double, float>(h, (const double *)h->coef, const_cast<double *>(x), 2, shift, r32, b, 0.0, 0.0, h->part)
+    int rc = h->ring ? jvp2d_halo_t<double, double, double, float>(h, (const double *)h->coef, const_cast<double *>(x), 2, shift, r32, b, 0.0, 0.0, h->part)
                          : jvp2d_launch_t<double, double, double, float>(h, K, 1.0, (const double *)h->coef, x, 2, shift, r32, b, 0.0, 0.0, h->part);
     if (rc) return rc;
     return reduce_rows(h, 1, (int)nwaves, 0);
@@ -384,7 +385,7 @@ static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shi
 {
     const KGeom &G = h->G;
     KStrips K = make_strips(h, true);
-    if (h->size == 1) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta, normpart);
+    if (!h->ring) return jvp2d_launch_t(h, K, 1.0, C, v, mode, shift, out, yadd, alpha, beta, normpart);
     const long long scale = sizeof(double) / sizeof(TV);            // 1 for double, 2 for float
     const bool ovl = h->overlap && K.nseg >= 3;
     int rc;

@@ -311,7 +311,16 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_reduce_rows(const double *__rest
     __shared__ double red[KSFD_BLOCK / KSFD_WAVE];
     const double *row = part + (long long)blockIdx.x * nblk;
     double s = op ? -1.0e300 : 0.0;
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s = op ? fmax(s, row[b]) : s + row[b];
+    // eight loads in flight per thread (one memory latency per 8 x blockDim partials instead of one per blockDim: this kernel sits
+    // between every residual evaluation and the host's decision); the order of the additions is fixed by the code, so results stay
+    // bitwise reproducible from run to run
+    for (int b0 = threadIdx.x; b0 < nblk; b0 += 8 * blockDim.x) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int b = b0 + q * blockDim.x; t[q] = b < nblk ? row[b] : (op ? -1.0e300 : 0.0); }
+#pragma unroll
+        for (int q = 0; q < 8; q++) s = op ? fmax(s, t[q]) : s + t[q];
+    }
     s = op ? ksfd_wave_max(s) : ksfd_wave_sum(s);
     if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) red[threadIdx.x / KSFD_WAVE] = s;
     __syncthreads();

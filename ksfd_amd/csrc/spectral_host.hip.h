@@ -77,8 +77,9 @@ static void spec_build3d(ksfd_handle *h)
     const KGeom &G = h->G;
     const int P = h->size;
     if (getenv("KSFD_SPEC_NO3D")) return;
-    if (P == 1 && G.ng != 0) return;
-    if (P > 1 && (!h->tr || !h->tr->has_alltoall() || (P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
+    const bool ring = h->ring;                                     // slab layout + all-to-alls (also a ring of ONE rank: every piece is its own)
+    if (!ring && G.ng != 0) return;
+    if (ring && (!h->tr || !h->tr->has_alltoall() || (P != 1 && P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
     const long long nzg = h->cfg.n[2], nzl = G.sloc;               // global / local z planes
     if (!spec_plan(G.nx, S.px) || !spec_plan(G.ny, S.py) || !spec_plan(nzg, S.pz)) return;
     if (S.px.radix[0] != 16 || G.nx > 32768 || G.ny > 32768 || (nzl & (nzl - 1)) || nzl < 2) return;
@@ -126,7 +127,7 @@ static void spec_build3d(ksfd_handle *h)
     S.nxl = nx / P;
     S.lg_pl = 0;
     while ((1LL << S.lg_pl) < nzl) S.lg_pl++;
-    auto local_index = [&](int j) { return P == 1 ? j : dig_idx[j / nx16] * nx16 + (j % nx16); };
+    auto local_index = [&](int j) { return !ring ? j : dig_idx[j / nx16] * nx16 + (j % nx16); };
     // pairs of columns {(kx,ky), (-kx,-ky)}; a column is addressed by its (local) position pair
     const std::vector<int> posx = spec_positions(S.px), posy = spec_positions(S.py);
     std::vector<int4> ent;
@@ -155,7 +156,7 @@ static void spec_build3d(ksfd_handle *h)
         if (!spec_upload(&tz, spec_twiddles(S.pz.n))) { hipGetLastError(); spec_free(h); return; }
         S.twz = tz;
     } else S.twz = S.twy;
-    if (P > 1) {
+    if (ring) {
         // pieces of the two all-to-alls: one per (peer, pair, top digit of the receiver) = nx/16 positions x ny x nzl, contiguous on both sides
         const size_t pel = (size_t)nx16 * ny * nzl, pbytes = sizeof(kcf) * pel;
         for (int q = 0; q < P; q++)
@@ -183,7 +184,8 @@ static void spec_build(ksfd_handle *h)
     S.ok = false;
     if (G.dim == 3) { spec_build3d(h); return; }
     if (G.dim != 2) return;
-    if (P > 1 && (!h->tr || !h->tr->has_alltoall() || (P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
+    const bool ring = h->ring;                                       // slab layout + all-to-alls (also a ring of ONE rank: every piece is its own)
+    if (ring && (!h->tr || !h->tr->has_alltoall() || (P != 1 && P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
     const long long ny = h->cfg.n[1], nyl = G.sloc;                  // global / local rows
     if (!spec_plan(G.nx, S.px) || !spec_plan(ny, S.py)) return;
     if (S.px.radix[0] != 16 || (nyl & (nyl - 1)) || nyl < 4) return;
@@ -234,7 +236,7 @@ static void spec_build(ksfd_handle *h)
     while ((1LL << S.lg_pl) < nyl) S.lg_pl++;
     const std::vector<int> posx = positions(S.px);
     // among the owner's positions (one rank: the work array is used in place, positions are their own index)
-    auto local_index = [&](int j) { return P == 1 ? j : dig_idx[j / nx16] * nx16 + (j % nx16); };
+    auto local_index = [&](int j) { return !ring ? j : dig_idx[j / nx16] * nx16 + (j % nx16); };
     std::vector<int4> pairs;
     for (int kx = 0; kx <= nx / 2; kx++) {
         const int kxm = (nx - kx) % nx, j = posx[kx], jm = posx[kxm];
@@ -249,12 +251,12 @@ static void spec_build(ksfd_handle *h)
     if (S.nblk_cols != S.nxl / 2) return;                            // (cannot happen for P in {1, 2, 4, 8}: the digit pairs keep kx and -kx together)
     const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nyl;
     S.nyp = (int)nyl;
-    S.tile_major = P == 1 && rb >= 2 && !getenv("KSFD_SPEC_TRANSPOSED");
-    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || ((P > 1 || S.tile_major || S.cols_split) && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
+    S.tile_major = !ring && rb >= 2 && !getenv("KSFD_SPEC_TRANSPOSED");
+    if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || ((ring || S.tile_major || S.cols_split) && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
         !spec_upload(&S.twx, twiddles(S.px.n)) || !spec_upload(&S.twy, twiddles(S.py.n)) ||
         !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) || !spec_upload(&S.pairtab, pairs) ||
         !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1]))) { hipGetLastError(); spec_free(h); return; }
-    if (P > 1) {
+    if (ring) {
         // pieces of the two all-to-alls: one per (peer, pair, top digit of the receiver) = nx/16 columns x nyl rows, contiguous on both sides
         const size_t pbytes = sizeof(kcf) * (size_t)nx16 * nyl;
         for (int q = 0; q < P; q++)
@@ -361,7 +363,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
                                (const kcf *)S.W2, S.W, (const kcf *)S.twy);
         }
         kcf *Wz = S.W;
-        if (h->size > 1) {                                            // z planes of everybody's columns -> whole z columns of mine
+        if (h->ring) {                                                // z planes of everybody's columns -> whole z columns of mine
             Scope sc(h, KC_HALO, pn);
             if (h->tr->alltoall(S.a2a_fwd_s, S.a2a_fwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
             Wz = S.W2;
@@ -374,7 +376,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
             if (S.npair == 1) KSPEC_Z_LAUNCH(1); else if (S.npair == 2) KSPEC_Z_LAUNCH(2); else KSPEC_Z_LAUNCH(0);
 #undef KSPEC_Z_LAUNCH
         }
-        if (h->size > 1) {
+        if (h->ring) {
             Scope sc(h, KC_HALO, pn);
             if (h->tr->alltoall(S.a2a_bwd_s, S.a2a_bwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
         }
@@ -386,7 +388,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         // the inverse x rows read W3 = S.W2 ([pair][pos_x][z*ny + y]) below
     } else {
     kcf *Wc = S.W;
-    if (h->size > 1) {                                                // rows of everybody's columns -> whole columns of mine
+    if (h->ring) {                                                    // rows of everybody's columns -> whole columns of mine
         Scope sc(h, KC_HALO, pn);
         if (h->tr->alltoall(S.a2a_fwd_s, S.a2a_fwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
         Wc = S.W2;
@@ -398,7 +400,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         while ((1 << lg_rb) < S.rb) lg_rb++;
         if (S.cols_split) {
             // one rank: tiles (W2) -> spectrum (W) -> result (W2); slab ranks: in place in W2, then result into W as scratch
-            kcf *spec = h->size > 1 ? S.W2 : S.W, *res = h->size > 1 ? S.W : S.W2;
+            kcf *spec = h->ring ? S.W2 : S.W, *res = h->ring ? S.W : S.W2;
             for (int phase = 1; phase <= 2; phase++)
                 hipLaunchKernelGGL(k_spec_cols_split, dim3((unsigned)S.nblk_cols, (unsigned)S.npair), dim3(thr_cols), S.lds_cols, h->st, phase, py_c, S.nxl, S.lg_pl, pstride, spec,
                                    (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, res, (const kcf *)S.twy,
@@ -411,7 +413,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
 #undef KSPEC_COLS_LAUNCH
         }
     }
-    if (h->size > 1) {
+    if (h->ring) {
         Scope sc(h, KC_HALO, pn);
         if (h->tr->alltoall(S.a2a_bwd_s, S.a2a_bwd_r, h->st)) return fail(h, KSFD_ECOMM, "spectral all-to-all failed: %s", h->tr->error().c_str());
     }

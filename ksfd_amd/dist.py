@@ -135,6 +135,58 @@ class HostRing:
         return d
 
 
+class SelfRing:
+    """transport-2 callbacks of a ring of ONE rank (the rank is its own lower and upper neighbour): no process group needed.
+    The handle then runs the whole slab code path -- ghost rows, halo exchange, reductions through the transport, the
+    all-to-all transposes of the spectral solver -- on a single GPU."""
+
+    def __init__(self):
+        self._ex = klib.EXCHANGE_FN(self._exchange)
+        self._ar = klib.ALLREDUCE_FN(lambda ctx, buf, count, op: 0)
+        self._a2a = klib.ALLTOALL_FN(self._alltoall)
+
+    @staticmethod
+    def _exchange(ctx, slo, shi, rlo, rhi, count):
+        n = int(count)
+        C.memmove(rhi, slo, 8 * n)          # send_lo goes to the lower neighbour's high ghost, send_hi to the upper one's low ghost:
+        C.memmove(rlo, shi, 8 * n)          # both neighbours are this rank
+        return 0
+
+    @staticmethod
+    def _alltoall(ctx, send, recv, bytes_per_peer):
+        C.memmove(recv, send, int(bytes_per_peer))
+        return 0
+
+    def cdist(self, device=0):
+        d = klib.CDist()
+        d.rank, d.size, d.transport, d.device = 0, 1, 2, device
+        d.nccl_id = None
+        d.exchange, d.allreduce, d.ctx = self._ex, self._ar, None
+        d.alltoall = self._a2a
+        return d
+
+
+def open_self_ring(cfg, device=0, transport='rccl'):
+    """One rank that is its own ring neighbour (ksfd_dist.size = 1 WITH a transport): ghost rows + halo exchange with itself,
+    one-rank all-reduces, own-piece all-to-alls.  transport 'rccl': a one-rank RCCL communicator inside the library
+    (ncclCommInitRank, grouped ncclSend/ncclRecv to self, ncclAllReduce, k_publish hand-over) -- the RCCL transport executed
+    end to end on a one-GPU box; 'host': the same through the host callbacks.  Returns (KSFDHip, keepalive)."""
+    if transport == 'rccl':
+        buf = C.create_string_buffer(klib.rccl_unique_id(), 128)
+        d = klib.CDist()
+        d.rank, d.size, d.transport, d.device = 0, 1, 1, device
+        d.nccl_id = C.cast(buf, C.c_void_p)
+        d._keepalive = buf
+        ks = klib.KSFDHip(cfg, d)
+        ks.transport_name, ks.rccl_error = 'rccl-self', None
+        return ks, d
+    ring = SelfRing()
+    ks = klib.KSFDHip(cfg, ring.cdist(device))
+    ks._ring = ring
+    ks.transport_name, ks.rccl_error = 'host-self', None
+    return ks, ring
+
+
 def rccl_cdist(rank, size, device, group=None, unique_id=None):
     """transport 1: rank 0 creates the ncclUniqueId, torch.distributed broadcasts it (through `group`: pass the host/gloo
     group when the default one is NCCL, so no device tensor is involved before the library's own communicator exists)."""

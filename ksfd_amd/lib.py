@@ -53,7 +53,9 @@ class StepOpts(C.Structure):
 class StepStats(C.Structure):
     _fields_ = [('accepted', C.c_int32), ('rejections', C.c_int32), ('linear_its', C.c_int32),
                 ('rhs_evals', C.c_int32), ('jvp_evals', C.c_int32), ('pc_used', C.c_int32),
-                ('wrms', C.c_double), ('h_used', C.c_double), ('ksp_resid', C.c_double), ('bytes', C.c_double)]
+                ('wrms', C.c_double), ('h_used', C.c_double), ('ksp_resid', C.c_double), ('bytes', C.c_double),
+                ('launches', C.c_int32), ('host_syncs', C.c_int32), ('residual_evals', C.c_int32),
+                ('predicted_final', C.c_int32)]
 
 
 class Profile(C.Structure):

@@ -32,7 +32,7 @@ def test_struct_sizes_match_header():
     # ksfd_config: 4*int32 + 3*int64 + 3*double + 6*double + 7 pointers
     assert ctypes.sizeof(klib.CConfig) == 16 + 24 + 24 + 48 + 56
     assert ctypes.sizeof(klib.StepOpts) == 8 * 2 + 8 + 8 * 8 + 16
-    assert ctypes.sizeof(klib.StepStats) == 24 + 32
+    assert ctypes.sizeof(klib.StepStats) == 24 + 32 + 16
     assert ctypes.sizeof(klib.Profile) == klib.NKCLASS * 8 * 4 and klib.NKCLASS == 14
 
 

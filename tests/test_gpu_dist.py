@@ -126,6 +126,73 @@ def test_slab_ranks_match_single_rank_rccl(tmp_path):
     _run(2, (64, 48), 1, 'rccl', tmp_path)
 
 
+def _ring_of_one_case(transport, shape, nlig):
+    """everything a slab rank does, on ONE rank that is its own ring neighbour, against the plain (wrap-index) handle"""
+    from ksfd_amd import lib as klib
+    from ksfd_amd.dist import open_self_ring, transport_selftest, reduction_selftest, spectral_selftest
+    dim = len(shape)
+    pow2 = all(n & (n - 1) == 0 for n in shape)
+    cfg = ProblemConfig.standard(dim, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=nlig)
+    rng = np.random.default_rng(3)
+    N = cfg.N
+    rho = 9000 + 90 * rng.standard_normal(N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] * (1 + 0.01 * rng.standard_normal(N)) for l in range(nlig)])
+    v = rng.standard_normal(cfg.F * N)
+    ks, keep = open_self_ring(cfg, 0, transport)
+    one = klib.KSFDHip(cfg)
+    try:
+        # the checks open_handle runs on a new multi-rank handle
+        assert transport_selftest(ks, cfg, 0, 1)
+        assert reduction_selftest(ks, cfg, 0, 1)
+        assert spectral_selftest(ks, cfg, 0, 1)
+        assert rel_l2(ks.rhs(u), one.rhs(u)) < 1e-13
+        assert rel_l2(ks.jvp(v, u), one.jvp(v, u)) < 1e-13
+        ks.set_state(u), one.set_state(u)
+        assert np.allclose(ks.velocity_max(), one.velocity_max(), rtol=1e-12, atol=0)
+        assert abs(ks.count_worms() - one.count_worms()) <= 1e-12 * one.count_worms()
+        if pow2 and dim >= 2:
+            assert rel_l2(ks.spectral_apply(3.0, v), one.spectral_apply(3.0, v)) < 1e-5      # fp32 transforms, different summation order
+        opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=1e-11)
+        t, h, t1, h1 = 0.0, 0.02, 0.0, 0.02
+        for _ in range(3):
+            t, h, st, rc = ks.step(t, h, opts)
+            t1, h1, st1, rc = one.step(t1, h1, opts)
+            assert st.accepted == st1.accepted and st.rejections == st1.rejections
+        assert np.allclose([t, h], [t1, h1], rtol=1e-9, atol=0)
+        assert rel_l2(ks.get_state(), one.get_state()) < 1e-9
+        if pow2 and dim >= 2:
+            # a step through the slab-distributed spectral solver: all-to-all transposes whose every piece is this rank's own
+            sp = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=4)
+            t, h, st, rc = ks.step(t, 0.3, sp)
+            t1, h1, st1, rc = one.step(t1, 0.3, sp)
+            assert st.pc_used & 8 and st1.pc_used & 8
+            assert rel_l2(ks.get_state(), one.get_state()) < 1e-9
+        stiff = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-11, pc_type=1)
+        t, h, st, rc = ks.step(t, 5.0, stiff)
+        t1, h1, st1, rc = one.step(t1, 5.0, stiff)
+        assert rel_l2(ks.get_state(), one.get_state()) < 1e-9
+        return ks.transport_name
+    finally:
+        ks.close()
+        one.close()
+
+
+RING1_CASES = [((64, 48), 1), ((64, 64), 2), ((140, 160), 1), ((32, 32, 32), 1), ((96,), 2)]
+
+
+@pytest.mark.parametrize('shape,nlig', RING1_CASES)
+def test_ring_of_one_rccl_transport_matches_wrap_index_handle(shape, nlig):
+    """The RCCL transport EXECUTED on the one-GPU box: ksfd_dist{size = 1, transport = 1} -> ncclCommInitRank over one rank, ghost rows
+    filled by grouped ncclSend/ncclRecv to itself (on the second stream, behind the interior row segments, where the grid has >= 3
+    segments), ncclAllReduce + the k_publish hand-over of every reduction, the own-piece path of the spectral all-to-alls."""
+    assert _ring_of_one_case('rccl', shape, nlig) == 'rccl-self'
+
+
+@pytest.mark.parametrize('shape,nlig', RING1_CASES[:3])
+def test_ring_of_one_host_transport_matches_wrap_index_handle(shape, nlig):
+    assert _ring_of_one_case('host', shape, nlig) == 'host-self'
+
+
 # The stage systems are solved to a tolerance; which iteration crosses it can differ between rank counts (different
 # summation order), so a comparison tighter than the default ksp_rtol=1e-6 needs a tighter solve.
 TIGHT = ('--petsc', '-ksp_rtol', '1e-11', '--')

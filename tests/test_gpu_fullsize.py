@@ -89,6 +89,59 @@ def test_step_of_a_tiled_state_is_the_tiled_step():
     assert rel_l2(got[:big.N], tile(us)[:big.N]) > 1e-6
 
 
+def test_pinned_window_of_the_bench_at_4096_with_the_default_ksp_rtol():
+    """Parity in the regime AND at the size the driver's bench measures.  The bench problem at 512^2 (options84 spacing/physics, the
+    synthetic start values of SURVEY.md 8d) is advanced adaptively from dt0 = 1e-8 to the start of the pinned window (t* >= 0.35,
+    ksp_rtol = 1e-12), that state is tiled 8x8 to 4096^2 -- same spacing, so the tiling is an exact solution of the big problem --
+    and the window's five adaptive steps (h = 0.11 ... 0.32) are taken
+      * on the 512^2 tile with ksp_rtol = 1e-12 (which the small-size tests tie to the oracle's exact sparse-LU step), and
+      * on 4096^2 with the library DEFAULTS (ksp_rtol = 1e-6, spectral defect correction with its predicted last sweep),
+    followed by one fixed step that lands both runs on the same model time.  Same accept/reject sequence, step sizes within 1e-3,
+    fields within the north-star tolerance 1e-8 rel-L2 (the reference solves these systems exactly: options84:58-60)."""
+    from ksfd_amd.initial import reference_rng
+    small, big = _cfg((512, 512), 1), _cfg((4096, 4096), 1)
+    zc = reference_rng().normal(size=(128, 128)) * 90.0
+    tight = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, ksp_rtol=1e-12)
+    dflt = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6)                 # options84:18-19, everything else as shipped
+    assert dflt.ksp_rtol == 1e-6 and dflt.pc_type == 2
+    ks = klib.KSFDHip(small)
+    ks.set_state_random(zc, 9000.0)
+    t, h = 0.0, 1e-8
+    while t < 0.35:
+        t, h, st, rc = ks.step(t, h, tight)
+    t_star, h_star, u_star = t, h, ks.get_state()
+
+    def window(k, opts, t_land=None):
+        t, h, hs, acc = t_star, h_star, [], []
+        for _ in range(5):
+            t, h, st, rc = k.step(t, h, opts)
+            hs.append(st.h_used)
+            acc.append((st.accepted, st.rejections))
+        if t_land is None:
+            t_land = t + 0.5 * h
+        fixed = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=opts.ksp_rtol)
+        t2, _, st, rc = k.step(t, t_land - t, fixed)
+        assert abs(t2 - t_land) < 1e-12
+        return np.array(hs), acc, t_land, st
+
+    hs_ref, acc_ref, t_land, _ = window(ks, tight)
+    want = _tile(ks.get_state(), 2, (512, 512), 8)
+    ks.close()
+    assert 0.1 < hs_ref.min() and hs_ref.max() > 0.25, hs_ref                    # the bench's window
+    kb = klib.KSFDHip(big)
+    kb.set_state(_tile(u_star, 2, (512, 512), 8))
+    hs_got, acc_got, _, st_last = window(kb, dflt, t_land)
+    got = kb.get_state()
+    kb.close()
+    assert st_last.pc_used & 8 and st_last.predicted_final > 0                   # the solver path the bench times
+    drift = np.abs(hs_got / hs_ref - 1.0).max()
+    err = rel_l2(got, want)
+    print('pinned window at 4096^2, default ksp_rtol vs 512^2 tile at 1e-12: step-size drift %.2e, fields %.2e' % (drift, err))
+    assert acc_got == acc_ref
+    assert drift < 1e-3, (hs_got, hs_ref)
+    assert err < 1e-8, err
+
+
 def _tile(x, F, small_shape, reps):
     """periodic replication of a flat SoA state: (F, [nz,] ny, nx) tiled `reps` times along every axis"""
     a = x.reshape((F,) + tuple(reversed(small_shape)))

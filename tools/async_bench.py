@@ -8,4 +8,4 @@ for n in (512, 1024, 2048, 4096):
         if not line:
             print(n, name, 'FAILED', out[-300:]); continue
         d = json.loads(line[-1])
-        print('n %5d %-5s ms/step %8.3f its/step %.1f value %.3e' % (n, name, d['ms_per_step'], d['config']['gmres_its_per_step'], d['value']), flush=True)
+        print('n %5d %-5s ms/step %8.3f its/step %.1f value %.3e' % (n, name, d['ms_per_step'], d['config']['linear_its_per_step'], d['value']), flush=True)
