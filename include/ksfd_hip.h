@@ -96,10 +96,11 @@ typedef struct ksfd_step_opts {
     double safety, reject_safety; /* 0.9, 0.5 */
     double ksp_rtol, ksp_atol;  /* GMRES: stop at ||r|| <= max(ksp_rtol*||b||, ksp_atol) */
     int32_t ksp_restart, ksp_max_it;
-    int32_t pc_type;            /* 0 none; 1 geometric multigrid V cycle always; 2 automatic (default): the spectral preconditioner
-                                 * (constant-coefficient part of shift*I - J inverted by FFT; 2-D, power-of-two grid, one rank) while
-                                 * it converges in a few iterations, else multigrid when the step is stiff, Chebyshev polynomial +
-                                 * flexible GMRES when mildly stiff, none when not; 3 polynomial only; 4 spectral always */
+    int32_t pc_type;            /* 0 none; 1 geometric multigrid V cycle always; 2 automatic (default): the spectral defect correction
+                                 * (constant-coefficient part of shift*I - J inverted by FFT; 2-D and 3-D, extents 2^k or 3*2^k, on 1, 2,
+                                 * 4 or 8 slab ranks) while it converges in a few sweeps, else multigrid when the step is stiff,
+                                 * Chebyshev polynomial + flexible GMRES when mildly stiff, none when not; 3 polynomial only;
+                                 * 4 spectral always */
     int32_t reserved;           /* flags.  bit 0: classic two-pass CGS2 instead of CGS2 with the algebraic second projection;
                                  * bit 1: single attempt per call -- a rejected step returns with accepted = 0 and *hstep = the
                                  * controller's proposal (callers that must refresh stage-time data per attempt);
@@ -250,9 +251,10 @@ int ksfd_set_mg_params(ksfd_handle *h, int32_t nu, int32_t ncoarse_max, int32_t 
 int ksfd_set_poly_params(ksfd_handle *h, int32_t max_degree, double target, double mg_threshold);
 /* Spectral preconditioner: z = (shift*I - J0)^-1 v with J0 the constant-coefficient part of the Jacobian at the resident state
  * (grid means of rho*G_rho, rho*G_Ul; the 4th-order star's exact symbol), three hand-written FFT kernels (csrc/spectral.hip.h).
- * _apply is the parity/test entry (host vectors; KSFD_EINVAL where the handle cannot use it: 1-D/3-D, several ranks, extents
- * that are not powers of two in 32..16384).  _params: stiffness h*gamma*lambda_max(diffusion) from which pc_type 2 prefers it
- * (default 0.3; <= 0 keeps) and enable (0 = never pick it automatically, 1 = default, < 0 keeps). */
+ * _apply is the parity/test entry (host vectors; KSFD_EINVAL where the handle has no spectral solver: 1-D, extents outside
+ * {2^k, 3*2^k} or 32..16384, rank counts other than 1, 2, 4, 8, a transport without an all-to-all).  _params: stiffness
+ * h*gamma*lambda_max(diffusion) from which pc_type 2 prefers it (default 0.1 where the fused 2-D residual kernel runs, 0.3
+ * elsewhere; <= 0 keeps) and enable (0 = never pick it automatically, 1 = default, < 0 keeps). */
 int ksfd_spectral_apply(ksfd_handle *h, double shift, const double *v_host, double *out_host, int32_t layout);
 int ksfd_set_spectral_params(ksfd_handle *h, double from_stiffness, int32_t enable);
 

@@ -41,6 +41,8 @@ struct SpecState {
     size_t lds_rows = 0, lds_cols = 0;
     kcf *W = nullptr, *W2 = nullptr, *twx = nullptr, *twy = nullptr, *twz = nullptr;     // W: [pair][pos_x][y_local]; W2: after the all-to-all, [rank][pair][own pos][y_local]
     int *posy = nullptr, *kyofpos = nullptr;
+    int2 *ytab = nullptr;                    // per y position: (position of -ky, bits of ly[ky]) -- symbol stage of k_spec_cols
+    int lgw = -1;                            // layout of the forward work array (kspec_wt_index)
     int4 *pairtab = nullptr;          // per block of the column kernel
     int nxl = 0, nblk_cols = 0, lg_pl = 0;   // owned positions, column-kernel blocks, log2(rows per rank)
     std::vector<A2APiece> a2a_fwd_s, a2a_fwd_r, a2a_bwd_s, a2a_bwd_r;

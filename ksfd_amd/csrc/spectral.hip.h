@@ -26,16 +26,44 @@
 // DIF forward leaves the spectrum in digit-reversed order and DIT inverse consumes exactly that order, so no permutation
 // pass exists anywhere; the symbol stage looks positions up in small tables (posx/posy).
 // HBM traffic per application: 8FN + 4FN | 4FN + 4FN | 4FN + 8FN = 32 F N bytes (algorithmic: read v, write z = 16 F N).
-// 2-D, power-of-two extents, single rank (a slab-distributed version needs an all-to-all transpose; not built).
+// 2-D (these kernels) and 3-D (k_spec3_*, below); one rank or 2, 4, 8 slab ranks (all-to-all transposes between the x- and the
+// y/z-transforms: spectral_host.hip.h).
 #pragma once
 
 typedef float2 kcf;
 #define KSPEC_MAXSTAGE 7
 struct KFFTPlan {
-    int n, lg, nstage;
-    int radix[KSPEC_MAXSTAGE];     // DIF stage order; prod = n
+    int n, lg, nstage;             // n = m << lg
+    int m;                         // 1, or 3: extents 3 * 2^lg (the reference's own 2-D grids are 384^2 and 1536^2, options81:17, options84:15).
+                                   // A radix-3 stage over the element stride 2^lg comes FIRST (DIF; last in the DIT inverse) and leaves three
+                                   // independent power-of-two transforms, which the stages below run as 3 * nseq sequences: in the LDS a
+                                   // sequence is m sub-sequences of 2^lg elements, kspec_ss() apart (kspec_lpos)
+    int radix[KSPEC_MAXSTAGE];     // DIF stage order of the power-of-two part; prod = 2^lg
     int flags;                     // kernel variants (spec_apply): bit0/bit1 = first/last stage of k_spec_cols fused with its loads/stores, bit2 = first stage of k_spec_rows_fwd<float>
+    int lgw;                       // layout of the forward work array on one rank (kspec_wt_index): < 0 tile-major, else log2 of the position group
 };
+
+// Element (tile, pos, r) of one field pair's forward work array (one rank: what the forward row kernel hands to the column kernel).
+//   lgw < 0 : tile-major            Wt[tile][pos][r]                       -- the row kernel's store is one contiguous run per tile
+//   lgw >= 0: position-group-major  Wg[pos >> lgw][tile][pos & (2^lgw - 1)][r]  with 2^lgw * rb * 8 B = one 128-B line per (group, tile):
+//             the row kernel stores whole lines 128 B apart, and the 2^lgw column blocks of a group -- neighbours in the launch, on
+//             one XCD -- read ONE contiguous region of ny * 2^lgw elements instead of lines strewn over the whole array at tile stride
+//             (measured 4096^2: column kernel 116 -> 103 us, row kernel unchanged)
+__device__ __forceinline__ long long kspec_wt_index(int lgw, int lg_rb, long long ntiles, int nxl, long long tile, int pos, int r)
+{
+    return lgw < 0 ? ((tile * nxl + pos) << lg_rb) + r
+                   : ((((long long)(pos >> lgw) * ntiles + tile) << (lgw + lg_rb)) + ((pos & ((1 << lgw) - 1)) << lg_rb) + r);
+}
+
+// LDS geometry of one sequence of P.n elements: m sub-sequences of 2^lg elements, each padded by one element per 16 (+1)
+__device__ __forceinline__ int kspec_ss(const KFFTPlan &P) { const int n2 = 1 << P.lg; return n2 + (n2 >> 4) + 1; }
+__device__ __forceinline__ int kspec_sstride(const KFFTPlan &P) { return P.m * kspec_ss(P); }
+__device__ __forceinline__ int kspec_lpos(const KFFTPlan &P, int e)      // padded position of element e
+{
+    if (P.m == 1) return e + (e >> 4);
+    const int b = e >> P.lg, i = e & ((1 << P.lg) - 1);
+    return b * kspec_ss(P) + i + (i >> 4);
+}
 
 // a few fp64 vectors with coefficients: added to the input of the forward row kernel / to the output of the inverse one
 struct KSpecLin {
@@ -116,6 +144,14 @@ template <int R, bool INV> __device__ __forceinline__ void kc_dft(kcf (&x)[R])
     }
 }
 
+// x[q] *= w1^q, q = 1 .. R-1 (running product; a product tree of depth log2 R measured the same: tools/spec_lab.hip)
+template <int R> __device__ __forceinline__ void kc_twiddle(kcf (&x)[R], kcf w1)
+{
+    kcf w = w1;
+#pragma unroll
+    for (int q = 1; q < R; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+}
+
 // One in-place stage over `nseq` sequences of length n held in LDS (padded index, `sstride` elements apart).
 // Forward (DIF): y_q = w_L^(i q) * DFT_R(x)_q ; inverse (DIT): x = IDFT_R( conj(w_L^(i q)) y_q ).  tw[k] = exp(-2 pi i k / n).
 // LG_S = log2 of the element stride S inside a butterfly, compile-time: the padded positions of the R elements are then
@@ -140,17 +176,11 @@ __device__ __forceinline__ void kspec_stage(kcf *lds, int sstride, int nseq, int
         if (!INV) {
             kc_dft<R, false>(x);
             if (LG_S > 0) {
-                const kcf w1 = tw[i << (lg_n - lg_L)];
-                kcf w = w1;
-#pragma unroll
-                for (int q = 1; q < R; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+                kc_twiddle<R>(x, tw[i << (lg_n - lg_L)]);
             }
         } else {
             if (LG_S > 0) {
-                const kcf w1 = kc_conj(tw[i << (lg_n - lg_L)]);
-                kcf w = w1;
-#pragma unroll
-                for (int q = 1; q < R; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+                kc_twiddle<R>(x, kc_conj(tw[i << (lg_n - lg_L)]));
             }
             kc_dft<R, true>(x);
         }
@@ -176,10 +206,7 @@ __device__ __forceinline__ void kspec_stage0_fwd_from_t(kcf *lds, int sstride, i
         for (int q = 0; q < 16; q++) x[q] = ld(s, i, q);              // element i + q S
         kc_dft<16, false>(x);
         if (LG_S > 0) {
-            const kcf w1 = tw[i];
-            kcf w = w1;
-#pragma unroll
-            for (int q = 1; q < 16; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+            kc_twiddle<16>(x, tw[i]);
         }
         kcf *b0 = lds + (long long)s * sstride + kspec_pad(i);
 #pragma unroll
@@ -198,10 +225,7 @@ __device__ __forceinline__ void kspec_stage0_inv_to_t(const kcf *lds, int sstrid
 #pragma unroll
         for (int q = 0; q < 16; q++) x[q] = b0[q * S + ((q * S) >> 4)];
         if (LG_S > 0) {
-            const kcf w1 = kc_conj(tw[i]);
-            kcf w = w1;
-#pragma unroll
-            for (int q = 1; q < 16; q++) { x[q] = kc_mul(x[q], w); w = kc_mul(w, w1); }
+            kc_twiddle<16>(x, kc_conj(tw[i]));
         }
         kc_dft<16, true>(x);
         st(s, i, x);                                   // the 16 outputs: elements i + q S, q = 0..15
@@ -250,9 +274,40 @@ __device__ __forceinline__ void kspec_stage_any(int radix, kcf *lds, int sstride
 }
 __device__ __forceinline__ int kspec_lg(int r) { return r == 16 ? 4 : (r == 8 ? 3 : (r == 4 ? 2 : 1)); }
 
-// all stages from `first` on; the caller has synchronised after filling the LDS; returns synchronised
+// The radix-3 stage of a 3 * 2^lg transform: butterflies over the elements {i, i + 2^lg, i + 2 * 2^lg}, i.e. the same index of the three
+// sub-sequences.  Forward (DIF): y_b = w_n^(i b) DFT3(x)_b; inverse (DIT): x = IDFT3(conj(w_n^(i b)) y_b).  tw3[i] = exp(-2 pi i i / n), i < 2^lg
+// (stored behind the power-of-two table: spec_twiddles).
+template <bool INV>
+__device__ __forceinline__ void kspec_stage3(kcf *lds, int ss, int nseq, int lg, const kcf *__restrict__ tw3)
+{
+    const float sq = 0.86602540378443865f;
+    const int total = nseq << lg;
+    for (int item = threadIdx.x; item < total; item += blockDim.x) {
+        const int s = item >> lg, i = item & ((1 << lg) - 1);
+        kcf *b0 = lds + (long long)s * 3 * ss + i + (i >> 4);
+        kcf x0 = b0[0], x1 = b0[ss], x2 = b0[2 * ss];
+        kcf w1 = tw3[i];
+        if (INV) w1 = kc_conj(w1);
+        const kcf w2 = kc_mul(w1, w1);
+        if (INV) { x1 = kc_mul(x1, w1); x2 = kc_mul(x2, w2); }
+        const kcf t = kc_add(x1, x2), u = kc_sub(x1, x2);
+        const kcf a = make_float2(x0.x - 0.5f * t.x, x0.y - 0.5f * t.y);
+        const kcf r = INV ? make_float2(-sq * u.y, sq * u.x) : make_float2(sq * u.y, -sq * u.x);      // (+-i) (sqrt 3 / 2) u
+        kcf y1 = kc_add(a, r), y2 = kc_sub(a, r);
+        if (!INV) { y1 = kc_mul(y1, w1); y2 = kc_mul(y2, w2); }
+        b0[0] = kc_add(x0, t); b0[ss] = y1; b0[2 * ss] = y2;
+    }
+}
+
+// all stages from `first` on (power-of-two plans only: first > 0 is the fused first stage); the caller has synchronised after filling the
+// LDS; returns synchronised.  sstride = kspec_sstride(P).
 __device__ __forceinline__ void kspec_fft_fwd(const KFFTPlan &P, kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw, int first = 0)
 {
+    if (P.m == 3) {
+        kspec_stage3<false>(lds, kspec_ss(P), nseq, P.lg, tw + (1 << P.lg));
+        __syncthreads();
+        sstride = kspec_ss(P); nseq *= 3;
+    }
     int lg_L = P.lg;
     for (int s = 0; s < first; s++) lg_L -= kspec_lg(P.radix[s]);
     for (int s = first; s < P.nstage; s++) {
@@ -261,13 +316,18 @@ __device__ __forceinline__ void kspec_fft_fwd(const KFFTPlan &P, kcf *lds, int s
         lg_L -= kspec_lg(P.radix[s]);
     }
 }
-// stages nstage-1 ... last (0 = all of them)
+// stages nstage-1 ... last (0 = all of them; last > 0: power-of-two plans, the fused last stage follows)
 __device__ __forceinline__ void kspec_fft_inv(const KFFTPlan &P, kcf *lds, int sstride, int nseq, const kcf *__restrict__ tw, int last = 0)
 {
+    const int ss = P.m == 3 ? kspec_ss(P) : sstride, ns = P.m == 3 ? 3 * nseq : nseq;
     int lg_L = 0;
     for (int s = P.nstage - 1; s >= last; s--) {
         lg_L += kspec_lg(P.radix[s]);
-        kspec_stage_any<true>(P.radix[s], lds, sstride, nseq, P.lg, lg_L, tw);
+        kspec_stage_any<true>(P.radix[s], lds, ss, ns, P.lg, lg_L, tw);
+        __syncthreads();
+    }
+    if (P.m == 3) {
+        kspec_stage3<true>(lds, ss, nseq, P.lg, tw + (1 << P.lg));
         __syncthreads();
     }
 }
@@ -289,16 +349,17 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
     const int y0 = kspec_tile(blockIdx.x, ntiles < 0 ? -ntiles : ntiles) * rb;
-    const int sstride = nx + (nx >> 4) + 1;
+    const int sstride = kspec_sstride(PX);
     const TIN *va = v + (long long)(2 * p) * plane + (long long)y0 * nx;
     const bool has_b = 2 * p + 1 < F;
     const TIN *vb = has_b ? va + plane : va;
     const int half = nx >> 1, lg_half = PX.lg - 1;
     const int lg_rb = 31 - __clz(rb);             // rb is a power of two (spec_build)
+    auto row_of = [&](int idx) { return PX.m == 1 ? idx >> lg_half : (idx >> lg_half) / 3; };      // idx / half
     // loads in batches of 4 items per thread, all issued before the first LDS store (one memory latency per batch, not per item).
     // fp32 input (the residual of the defect correction): first stage straight from global memory, 16 x 2 scalar loads in flight
     // per thread (85 -> 76 us in the solver; with fp64 input the same fusion is SLOWER, 118 -> 136 us, and stays off)
-    if (sizeof(TIN) == 4 && PX.nstage > 0 && PX.radix[0] == 16 && ex.n == 0 && (PX.flags & 4)) {
+    if (sizeof(TIN) == 4 && PX.m == 1 && PX.nstage > 0 && PX.radix[0] == 16 && ex.n == 0 && (PX.flags & 4)) {
         const int S0 = nx >> 4;
         kspec_stage0_fwd_from(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int i, int q) {
             const TIN *pa = va + (long long)r * nx + i, *pb = vb + (long long)r * nx + i;
@@ -316,7 +377,7 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
             const int idx = base + u * blockDim.x + threadIdx.x;
             a[u] = b[u] = make_double2(0.0, 0.0);
             if (idx < rb * half) {
-                const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
+                const int r = row_of(idx), x = 2 * (idx - r * half);
                 a[u] = ksfd_ld2(va + (long long)r * nx + x);
                 if (has_b) b[u] = ksfd_ld2(vb + (long long)r * nx + x);
                 for (int j = 0; j < ex.n; j++) {            // wave-uniform, usually 0
@@ -331,10 +392,10 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
         for (int u = 0; u < 4; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
             if (idx < rb * half) {
-                const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
+                const int r = row_of(idx), x = 2 * (idx - r * half);
                 kcf *row = kspec_lds + r * sstride;
-                row[kspec_pad(x)] = make_float2((float)a[u].x, (float)b[u].x);
-                row[kspec_pad(x + 1)] = make_float2((float)a[u].y, (float)b[u].y);
+                row[kspec_lpos(PX, x)] = make_float2((float)a[u].x, (float)b[u].x);
+                row[kspec_lpos(PX, x + 1)] = make_float2((float)a[u].y, (float)b[u].y);
             }
         }
     }
@@ -345,17 +406,26 @@ __global__ void __launch_bounds__(1024) k_spec_rows_fwd(KFFTPlan PX, int nyp /* 
         // one rank: TILE-MAJOR store Wt[pair][tile][pos][r] -- one contiguous run per block (the transposed store below writes
         // 32-B segments, 151 -> 95 us); the column kernel gathers its columns from the tiles instead (strided READS are cheap: the
         // four positions of a 128-B line belong to blocks that run side by side on one XCD)
-        kcf *Wt = W + ((long long)p * (-ntiles) + y0 / rb) * nx * rb;
-        for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
-            const int j = idx >> lg_rb, r = idx & (rb - 1);
-            Wt[idx] = kspec_lds[r * sstride + kspec_pad(j)];
+        const long long nt = -ntiles, t = y0 / rb;
+        kcf *Wt = W + (long long)p * nt * nx * rb;
+        if (PX.lgw < 0) {
+            Wt += t * nx * rb;
+            for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
+                const int j = idx >> lg_rb, r = idx & (rb - 1);
+                Wt[idx] = kspec_lds[r * sstride + kspec_lpos(PX, j)];
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
+                const int j = idx >> lg_rb, r = idx & (rb - 1);
+                Wt[kspec_wt_index(PX.lgw, lg_rb, nt, nx, t, j, r)] = kspec_lds[r * sstride + kspec_lpos(PX, j)];
+            }
         }
         return;
     }
     kcf *Wp = W + (long long)p * nx * nyp + y0;
     for (int idx = threadIdx.x; idx < rb * nx; idx += blockDim.x) {
         const int j = idx >> lg_rb, r = idx & (rb - 1);
-        Wp[(long long)j * nyp + r] = kspec_lds[r * sstride + kspec_pad(j)];
+        Wp[(long long)j * nyp + r] = kspec_lds[r * sstride + kspec_lpos(PX, j)];
     }
 }
 
@@ -367,7 +437,7 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
     extern __shared__ kcf kspec_lds[];
     const int nx = PX.n, p = blockIdx.y;
     const int y0 = kspec_tile(blockIdx.x, ntiles) * rb;
-    const int sstride = nx + (nx >> 4) + 1;
+    const int sstride = kspec_sstride(PX);
     const kcf *Wp = W + (long long)p * nx * nyp + y0;
     const int lg_rb = 31 - __clz(rb), lg_half = PX.lg - 1;
     for (int base = 0; base < rb * nx; base += 8 * blockDim.x) {
@@ -380,13 +450,13 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
-            if (idx < rb * nx) { const int j = idx >> lg_rb, r = idx & (rb - 1); kspec_lds[r * sstride + kspec_pad(j)] = t[u]; }
+            if (idx < rb * nx) { const int j = idx >> lg_rb, r = idx & (rb - 1); kspec_lds[r * sstride + kspec_lpos(PX, j)] = t[u]; }
         }
     }
     __syncthreads();
     const bool has_b = 2 * p + 1 < F;
     const long long o0 = (long long)(2 * p) * plane + (long long)y0 * nx;
-    if (PX.nstage > 0 && PX.radix[0] == 16) {
+    if (PX.m == 1 && PX.nstage > 0 && PX.radix[0] == 16) {
         kspec_fft_inv(PX, kspec_lds, sstride, rb, tw, 1);
         const int S0 = nx >> 4;
         kspec_stage0_inv_to(kspec_lds, sstride, rb, PX.lg, tw, [&](int r, int i, kcf (&c)[16]) {
@@ -417,9 +487,9 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
     kspec_fft_inv(PX, kspec_lds, sstride, rb, tw);       // plans that do not start with radix 16 (experiment knob) / no transform (KSFD_SPEC_DIAG)
     const int half = nx >> 1;
     for (int idx = threadIdx.x; idx < rb * half; idx += blockDim.x) {
-        const int r = idx >> lg_half, x = 2 * (idx & (half - 1));
+        const int r = PX.m == 1 ? idx >> lg_half : (idx >> lg_half) / 3, x = 2 * (idx - r * half);
         const kcf *row = kspec_lds + r * sstride;
-        const kcf c0 = row[kspec_pad(x)], c1 = row[kspec_pad(x + 1)];
+        const kcf c0 = row[kspec_lpos(PX, x)], c1 = row[kspec_lpos(PX, x + 1)];
         const long long o = o0 + (long long)r * nx + x;
         double2 a = make_double2((double)c0.x, (double)c1.x), b = make_double2((double)c0.y, (double)c1.y);
         for (int j = 0; j < add.n; j++) {
@@ -485,25 +555,50 @@ __device__ __forceinline__ void kspec_symbol(const KSpecSym &S, float L2, kcf (&
 // order of ky so that both LDS accesses of a wave are consecutive (the partner positions of consecutive positions run backwards)
 template <int NL>
 __device__ __forceinline__ void kspec_cols_symbol(const KFFTPlan &PY, kcf *lds, int sstride, bool self, int kxA, int kxB, const int *__restrict__ posy,
-                                                  const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly, const KSpecSym &S)
+                                                  const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly,
+                                                  const int2 *__restrict__ ytab, const KSpecSym &S)
 {
     constexpr int F = NL + 1, npair = (F + 1) / 2;
     const int ny = PY.n, half = ny >> 1;
-    const int nitem = self ? 2 * ny : ny;
-    for (int item = threadIdx.x; item < nitem; item += blockDim.x) {
-        const int mpos = item & (ny - 1);
+    if (!self) {
+        // every block but one.  ytab[pos] = (position of -ky, bits of ly[ky]) for ky = the wavenumber AT position pos: one coalesced
+        // 8-B load per item, issued four items ahead -- the chain kyofpos[pos] -> posy[-ky], ly[ky] of three scattered, dependent table
+        // look-ups per item was a quarter of the kernel (4096^2: 35 of 150 us with everything else in place)
+        const float lxa = lx[kxA];
+        for (int base = threadIdx.x; base < ny; base += 4 * blockDim.x) {
+            int2 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int mpos = base + u * blockDim.x; if (mpos < ny) t[u] = ytab[mpos]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int mpos = base + u * blockDim.x;
+                if (mpos >= ny) break;
+                const int m = kspec_lpos(PY, mpos), mp = kspec_lpos(PY, t[u].x);
+                const float L2 = lxa + __int_as_float(t[u].y);
+                kcf a[npair], b[npair];
+#pragma unroll
+                for (int p = 0; p < npair; p++) { a[p] = lds[(2 * p) * sstride + m]; b[p] = lds[(2 * p + 1) * sstride + mp]; }
+                kspec_symbol<NL>(S, L2, a, b);
+#pragma unroll
+                for (int p = 0; p < npair; p++) { lds[(2 * p) * sstride + m] = a[p]; lds[(2 * p + 1) * sstride + mp] = b[p]; }
+            }
+        }
+        return;
+    }
+    // the block of the two self-paired columns kx = 0 and kx = nx/2: (c, ky) and (c, -ky) are one item
+    for (int item = threadIdx.x; item < 2 * ny; item += blockDim.x) {
+        const int c = item >= ny, mpos = item - c * ny;
         const int ky = kyofpos[mpos];
-        int ca = 0, cb = 1;
-        if (self) { ca = cb = item >> PY.lg; if (ky > half) continue; }      // (c, ky) and (c, -ky) are one item
-        const int kym = (ny - ky) & (ny - 1);
-        const int m = kspec_pad(mpos), mp = kspec_pad(posy[kym]);
-        const float L2 = lx[ca ? kxB : kxA] + ly[ky];
+        if (ky > half) continue;
+        const int kym = ky ? ny - ky : 0;
+        const int m = kspec_lpos(PY, mpos), mp = kspec_lpos(PY, posy[kym]);
+        const float L2 = lx[c ? kxB : kxA] + ly[ky];
         kcf a[npair], b[npair];
 #pragma unroll
-        for (int p = 0; p < npair; p++) { a[p] = lds[(2 * p + ca) * sstride + m]; b[p] = lds[(2 * p + cb) * sstride + mp]; }
+        for (int p = 0; p < npair; p++) { a[p] = lds[(2 * p + c) * sstride + m]; b[p] = lds[(2 * p + c) * sstride + mp]; }
         kspec_symbol<NL>(S, L2, a, b);
 #pragma unroll
-        for (int p = 0; p < npair; p++) { lds[(2 * p + ca) * sstride + m] = a[p]; lds[(2 * p + cb) * sstride + mp] = b[p]; }
+        for (int p = 0; p < npair; p++) { lds[(2 * p + c) * sstride + m] = a[p]; lds[(2 * p + c) * sstride + mp] = b[p]; }
     }
 }
 // compile-time ligand count for the per-point register arrays of the symbol stage, chosen INSIDE the kernel: the transforms around it
@@ -520,7 +615,7 @@ __device__ __forceinline__ void kspec_cols_symbol(const KFFTPlan &PY, kcf *lds, 
 template <int NPAIR_T>
 __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ Wt, int lg_rb, const kcf *__restrict__ tw,
                                                    const int4 *__restrict__ pairtab, const int *__restrict__ posy, const int *__restrict__ kyofpos,
-                                                   const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
+                                                   const float *__restrict__ lx, const float *__restrict__ ly, const int2 *__restrict__ ytab, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
     const int npair = NPAIR_T ? NPAIR_T : (S.nlig + 2) / 2;
@@ -528,20 +623,21 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     const int4 pt = pairtab[kspec_tile(blockIdx.x, gridDim.x)];       // consecutive pairs (= neighbouring positions) on one XCD
     const bool self = pt.w != 0;                                // kx = 0 and kx = nx/2 are their own partners
     const int jA = pt.x, jB = pt.y, kxA = pt.z, kxB = self ? pt.w - 1 : pt.z;     // lx is even: lx[-kx] = lx[kx]
-    const int sstride = ny + (ny >> 4) + 1;
+    const int sstride = kspec_sstride(PY);
     const int nseq = 2 * npair;
     const int half = ny >> 1, lg_half = PY.lg - 1;
+    auto seq_of = [&](int idx) { return PY.m == 1 ? idx >> lg_half : (idx >> lg_half) / 3; };      // idx / half
     const int plmask = (1 << lg_pl) - 1;
     auto colat = [&](int s, int y) {                           // y even: a float4 never straddles two pieces
         return W + (long long)(y >> lg_pl) * pstride + (((long long)(s >> 1) * nxl + ((s & 1) ? jB : jA)) << lg_pl) + (y & plmask);
     };
-    const bool r16 = PY.nstage > 0 && PY.radix[0] == 16 && (lg_rb < 0 || (ny >> 4) >= (1 << lg_rb));      // (a tile never holds two butterfly elements)
+    const bool r16 = PY.m == 1 && PY.nstage > 0 && PY.radix[0] == 16 && (lg_rb < 0 || (ny >> 4) >= (1 << lg_rb));      // (a tile never holds two butterfly elements)
     if (r16 && (PY.flags & 1)) {
         // element y = i + q S0 (S0 = ny/16 >= 2^lg_rb and >= 2^lg_pl pieces are whole multiples): q moves by a constant stride
         const int S0 = ny >> 4;
-        const long long qs = lg_rb >= 0 ? (long long)S0 * nxl : (lg_pl >= PY.lg ? (long long)S0 : 0);
+        const long long qs = lg_rb >= 0 ? (PY.lgw < 0 ? (long long)S0 * nxl : (long long)S0 << PY.lgw) : (lg_pl >= PY.lg ? (long long)S0 : 0);
         kspec_stage0_fwd_from(kspec_lds, sstride, nseq, PY.lg, tw, [&](int s, int i, int q) {
-            const kcf *p0 = lg_rb >= 0 ? Wt + ((((long long)(s >> 1) * (ny >> lg_rb) + (i >> lg_rb)) * nxl + ((s & 1) ? jB : jA)) << lg_rb) + (i & ((1 << lg_rb) - 1))
+            const kcf *p0 = lg_rb >= 0 ? Wt + (long long)(s >> 1) * nxl * ny + kspec_wt_index(PY.lgw, lg_rb, ny >> lg_rb, nxl, i >> lg_rb, (s & 1) ? jB : jA, i & ((1 << lg_rb) - 1))
                                        : colat(s, i);
             return qs ? p0[q * qs] : *colat(s, i + q * S0);
         });
@@ -554,8 +650,8 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         for (int u = 0; u < 8; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
             if (idx < nseq * half) {
-                const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
-                t[u] = lg_rb >= 0 ? *reinterpret_cast<const float4 *>(Wt + ((((long long)(s >> 1) * (ny >> lg_rb) + (y >> lg_rb)) * nxl + ((s & 1) ? jB : jA)) << lg_rb) + (y & ((1 << lg_rb) - 1)))
+                const int s = seq_of(idx), y = 2 * (idx - s * half);
+                t[u] = lg_rb >= 0 ? *reinterpret_cast<const float4 *>(Wt + (long long)(s >> 1) * nxl * ny + kspec_wt_index(PY.lgw, lg_rb, ny >> lg_rb, nxl, y >> lg_rb, (s & 1) ? jB : jA, y & ((1 << lg_rb) - 1)))
                                    : *reinterpret_cast<const float4 *>(colat(s, y));
             }
         }
@@ -563,21 +659,21 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         for (int u = 0; u < 8; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
             if (idx < nseq * half) {
-                const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
+                const int s = seq_of(idx), y = 2 * (idx - s * half);
                 kcf *q = kspec_lds + s * sstride;
-                q[kspec_pad(y)] = make_float2(t[u].x, t[u].y);
-                q[kspec_pad(y + 1)] = make_float2(t[u].z, t[u].w);
+                q[kspec_lpos(PY, y)] = make_float2(t[u].x, t[u].y);
+                q[kspec_lpos(PY, y + 1)] = make_float2(t[u].z, t[u].w);
             }
         }
     }
     __syncthreads();
     kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
     }
-    if (NPAIR_T == 1) kspec_cols_symbol<1>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S);
+    if (NPAIR_T == 1) kspec_cols_symbol<1>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, ytab, S);
     else if (NPAIR_T == 2) {
-        if (S.nlig == 2) kspec_cols_symbol<2>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S);
-        else kspec_cols_symbol<3>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S);
-    } else { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol<NL>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, S))); }
+        if (S.nlig == 2) kspec_cols_symbol<2>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, ytab, S);
+        else kspec_cols_symbol<3>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, ytab, S);
+    } else { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol<NL>(PY, kspec_lds, sstride, self, kxA, kxB, posy, kyofpos, lx, ly, ytab, S))); }
     __syncthreads();
     if (r16 && (PY.flags & 2)) {
         kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw, 1);
@@ -591,13 +687,14 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     }
     kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
-        const int s = idx >> lg_half, y = 2 * (idx & (half - 1));
+        const int s = seq_of(idx), y = 2 * (idx - s * half);
         const kcf *q = kspec_lds + s * sstride;
-        const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
+        const kcf c0 = q[kspec_lpos(PY, y)], c1 = q[kspec_lpos(PY, y + 1)];
         *reinterpret_cast<float4 *>(colat(s, y)) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
 
+#ifndef KSPEC_LAB_MINIMAL      // (tools/spec_lab.hip builds the three plain 2-D kernels only)
 // Column kernel for field counts whose 2*npair columns do not fit the LDS together (8192^2 x 3 fields needs 278 KB): two launches
 // over blocks (column pair, FIELD pair = blockIdx.y), each holding only its own two columns.
 //   phase 1: forward transform, the spectrum written to W in column layout (read from the tiles Wt when lg_rb >= 0, else in place)
@@ -663,7 +760,7 @@ __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY
             if (idx < 2 * half) {
                 const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
                 t[u] = (phase == 1 && lg_rb >= 0)
-                           ? *reinterpret_cast<const float4 *>(Wt + ((((long long)p0 * (ny >> lg_rb) + (y >> lg_rb)) * nxl + (c ? jB : jA)) << lg_rb) + (y & ((1 << lg_rb) - 1)))
+                           ? *reinterpret_cast<const float4 *>(Wt + (long long)p0 * nxl * ny + kspec_wt_index(PY.lgw, lg_rb, ny >> lg_rb, nxl, y >> lg_rb, c ? jB : jA, y & ((1 << lg_rb) - 1)))
                            : *reinterpret_cast<const float4 *>(colat(W, c, y));
             }
         }
@@ -842,6 +939,8 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
         *reinterpret_cast<float4 *>(colptr(s) + zoff(z)) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
+
+#endif // KSPEC_LAB_MINIMAL
 
 // grid means of rho*G_rho and rho*G_Ul over the frozen coefficient planes C = [rho, G, G_rho, G_U1..] (once per step)
 template <int NL>

@@ -6,7 +6,7 @@
 static void spec_free(ksfd_handle *h)
 {
     SpecState &S = h->spec;
-    void *bufs[] = { S.W, S.W2, S.twx, S.twy, S.twz != S.twy ? S.twz : nullptr, S.posy, S.kyofpos, S.pairtab, S.lx, S.ly, S.posz, S.kzofpos, S.lz };
+    void *bufs[] = { S.W, S.W2, S.twx, S.twy, S.twz != S.twy ? S.twz : nullptr, S.posy, S.kyofpos, S.pairtab, S.lx, S.ly, S.posz, S.kzofpos, S.lz, S.ytab };
     for (void *b : bufs) if (b) hipFree(b);
     S = SpecState();
 }
@@ -32,6 +32,7 @@ static void spec_build3d(ksfd_handle *h)
     if (ring && (!h->tr || !h->tr->has_alltoall() || (P != 1 && P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
     const long long nzg = h->cfg.n[2], nzl = G.sloc;               // global / local z planes
     if (!spec_plan(G.nx, S.px) || !spec_plan(G.ny, S.py) || !spec_plan(nzg, S.pz)) return;
+    if (S.px.m != 1 || S.py.m != 1 || S.pz.m != 1) return;           // (3 * 2^k extents: 2-D, one rank so far)
     if (S.px.radix[0] != 16 || G.nx > 32768 || G.ny > 32768 || (nzl & (nzl - 1)) || nzl < 2) return;
     S.dim = 3;
     S.npair = (G.F + 1) / 2;
@@ -96,14 +97,14 @@ static void spec_build3d(ksfd_handle *h)
     S.nent = (int)ent.size();
     const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nrows;
     if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || hipMalloc((void **)&S.W2, wbytes) != hipSuccess ||
-        !spec_upload(&S.twx, spec_twiddles(S.px.n)) || !spec_upload(&S.twy, spec_twiddles(S.py.n)) ||
+        !spec_upload(&S.twx, spec_twiddles(S.px)) || !spec_upload(&S.twy, spec_twiddles(S.py)) ||
         !spec_upload(&S.posz, spec_positions(S.pz)) || !spec_upload(&S.kzofpos, spec_inverse(spec_positions(S.pz))) || !spec_upload(&S.pairtab, ent) ||
         !spec_upload(&S.lx, spec_symbol_table(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, spec_symbol_table(S.py.n, h->P.inv_h2[1])) ||
         !spec_upload(&S.lz, spec_symbol_table(S.pz.n, h->P.inv_h2[2]))) { hipGetLastError(); spec_free(h); return; }
     // the z transforms need their own twiddle table when nz differs from ny: kept behind twy in one allocation is not worth it
     if (nzg != G.ny) {
         kcf *tz = nullptr;
-        if (!spec_upload(&tz, spec_twiddles(S.pz.n))) { hipGetLastError(); spec_free(h); return; }
+        if (!spec_upload(&tz, spec_twiddles(S.pz))) { hipGetLastError(); spec_free(h); return; }
         S.twz = tz;
     } else S.twz = S.twy;
     if (ring) {
@@ -138,22 +139,26 @@ static void spec_build(ksfd_handle *h)
     if (ring && (!h->tr || !h->tr->has_alltoall() || (P != 1 && P != 2 && P != 4 && P != 8) || getenv("KSFD_SPEC_SINGLE"))) return;
     const long long ny = h->cfg.n[1], nyl = G.sloc;                  // global / local rows
     if (!spec_plan(G.nx, S.px) || !spec_plan(ny, S.py)) return;
-    if (S.px.radix[0] != 16 || (nyl & (nyl - 1)) || nyl < 4) return;
+    const bool pow2 = S.px.m == 1 && S.py.m == 1;
+    if (ring && (!pow2 || S.px.radix[0] != 16 || (nyl & (nyl - 1)))) return;      // slab ownership goes by the top radix-16 digit
+    if (nyl < 4) return;
     S.npair = (G.F + 1) / 2;
     const size_t lds_max = 160 * 1024;
-    const size_t row_bytes = sizeof(kcf) * (size_t)(G.nx + (G.nx >> 4) + 1);
+    const size_t row_bytes = sizeof(kcf) * spec_sstride(S.px);
     int rb = (int)std::min<size_t>((lds_max - 1024) / row_bytes, 16);
-    while (rb > 1 && (nyl % rb)) rb--;                               // power-of-two rows: rb ends up a power of two
+    while (rb & (rb - 1)) rb &= rb - 1;                              // a power of two ...
+    while (rb > 1 && (nyl % rb)) rb >>= 1;                           // ... that divides the rows
     if (rb < 1) return;
     // rows per block: as many as the LDS holds (wider store segments of the transposed write), but keep >= 2 tiles per CU
     while (rb > 2 && nyl / rb < 512) rb >>= 1;
     if (getenv("KSFD_SPEC_RB")) rb = std::max(1, std::min(rb, atoi(getenv("KSFD_SPEC_RB"))));
     S.rb = rb;
     S.lds_rows = row_bytes * rb;
-    S.lds_cols = sizeof(kcf) * (size_t)(ny + (ny >> 4) + 1) * 2 * S.npair;
+    S.lds_cols = sizeof(kcf) * spec_sstride(S.py) * 2 * S.npair;
     S.cols_split = S.lds_cols > lds_max - 1024 || (getenv("KSFD_SPEC_SPLIT") && S.npair > 1);      // (the knob: tests of the split path on small grids)
-    if (S.cols_split) S.lds_cols = sizeof(kcf) * (size_t)(ny + (ny >> 4) + 1) * 2;                  // one field pair per block
+    if (S.cols_split) S.lds_cols = sizeof(kcf) * spec_sstride(S.py) * 2;                            // one field pair per block
     if (S.lds_cols > lds_max - 1024) return;
+    if (S.cols_split && !pow2) return;                               // (the two-phase column kernel is power-of-two only)
     if (hipFuncSetAttribute((const void *)k_spec_rows_fwd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_spec_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess) { hipGetLastError(); return; }
@@ -165,11 +170,6 @@ static void spec_build(ksfd_handle *h)
                                         : hipFuncSetAttribute((const void *)k_spec_cols<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_cols);
         if (e != hipSuccess) { hipGetLastError(); return; }
     }
-    auto twiddles = [](int n) {
-        std::vector<kcf> t(n);
-        for (int k = 0; k < n; k++) { const double a = -2.0 * M_PI * k / n; t[k] = make_float2((float)cos(a), (float)sin(a)); }
-        return t;
-    };
     auto positions = [](const KFFTPlan &Q) { std::vector<int> p(Q.n); for (int k = 0; k < Q.n; k++) p[k] = spec_pos(Q, k); return p; };
     auto inverse = [](const std::vector<int> &p) { std::vector<int> q(p.size()); for (size_t k = 0; k < p.size(); k++) q[p[k]] = (int)k; return q; };
     auto symbol = [](int n, double inv_h2) {
@@ -199,13 +199,26 @@ static void spec_build(ksfd_handle *h)
     std::sort(pairs.begin(), pairs.end(), [](const int4 &a, const int4 &b) { return a.x < b.x; });
     S.nblk_cols = (int)pairs.size();
     if (S.nblk_cols != S.nxl / 2) return;                            // (cannot happen for P in {1, 2, 4, 8}: the digit pairs keep kx and -kx together)
-    const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * nyl;
-    S.nyp = (int)nyl;
+    // column stride of W: the rows of this rank, rounded up to the power of two the column kernel addresses pieces with (equal for 2^k rows)
+    const long long cstride = ring ? nyl : (1LL << S.lg_pl);
+    const size_t wbytes = sizeof(kcf) * (size_t)S.npair * G.nx * cstride;
+    S.nyp = (int)cstride;
     S.tile_major = !ring && rb >= 2 && !getenv("KSFD_SPEC_TRANSPOSED");
     if (hipMalloc((void **)&S.W, wbytes) != hipSuccess || ((ring || S.tile_major || S.cols_split) && hipMalloc((void **)&S.W2, wbytes) != hipSuccess) ||
-        !spec_upload(&S.twx, twiddles(S.px.n)) || !spec_upload(&S.twy, twiddles(S.py.n)) ||
+        !spec_upload(&S.twx, spec_twiddles(S.px)) || !spec_upload(&S.twy, spec_twiddles(S.py)) ||
         !spec_upload(&S.posy, positions(S.py)) || !spec_upload(&S.kyofpos, inverse(positions(S.py))) || !spec_upload(&S.pairtab, pairs) ||
-        !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1]))) { hipGetLastError(); spec_free(h); return; }
+        !spec_upload(&S.lx, symbol(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, symbol(S.py.n, h->P.inv_h2[1])) ||
+        !spec_upload(&S.ytab, spec_partner_table(S.py, symbol(S.py.n, h->P.inv_h2[1])))) { hipGetLastError(); spec_free(h); return; }
+    // one rank: the forward work array is tile-major; KSFD_SPEC_LGW=<k> makes it position-group-major with groups of 2^k (kspec_wt_index;
+    // k = 2 at 4 rows per tile: one 128-B line per (group, tile).  Measured with the kernel laboratory at 4096^2 (tools/spec_lab.hip, median
+    // of 7 batches): row kernel 70 -> 74 us, column kernel 94 -> 96 us -- no gain once the symbol stage stopped waiting on table look-ups)
+    S.lgw = -1;
+    if (S.tile_major) {
+        int lg_rb = 0;
+        while ((1 << lg_rb) < rb) lg_rb++;
+        if (getenv("KSFD_SPEC_LGW")) S.lgw = std::max(-1, std::min(atoi(getenv("KSFD_SPEC_LGW")), 8));
+        if (S.lgw >= 0 && (S.nxl & ((1 << S.lgw) - 1))) S.lgw = -1;
+    }
     if (ring) {
         // pieces of the two all-to-alls: one per (peer, pair, top digit of the receiver) = nx/16 columns x nyl rows, contiguous on both sides
         const size_t pbytes = sizeof(kcf) * (size_t)nx16 * nyl;
@@ -291,6 +304,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     if (diag & 4) px_i.nstage = 0;
     static const int fuse = getenv("KSFD_SPEC_FUSE") ? atoi(getenv("KSFD_SPEC_FUSE")) : 7;
     px_f.flags = py_c.flags = px_i.flags = fuse;
+    px_f.lgw = py_c.lgw = d3 ? -1 : S.lgw;
     int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
     if (getenv("KSFD_SPEC_THRR")) thr_rows = atoi(getenv("KSFD_SPEC_THRR"));
     int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * (S.cols_split ? 1 : S.npair) * ny_glob / 16));
@@ -358,7 +372,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         } else {
 #define KSPEC_COLS_LAUNCH(NP) hipLaunchKernelGGL(k_spec_cols<NP>, dim3((unsigned)S.nblk_cols), dim3(thr_cols), S.lds_cols, h->st, py_c, S.nxl, S.lg_pl, pstride, Wc, \
                            (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, (const kcf *)S.twy, \
-                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y)
+                           (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, (const int2 *)S.ytab, Y)
             if (S.npair == 1) KSPEC_COLS_LAUNCH(1); else if (S.npair == 2) KSPEC_COLS_LAUNCH(2); else KSPEC_COLS_LAUNCH(0);
 #undef KSPEC_COLS_LAUNCH
         }

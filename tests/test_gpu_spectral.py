@@ -90,7 +90,10 @@ def _state(cfg, seed, amp=90.0):
 
 
 @pytest.mark.parametrize('shape,nlig', [((64, 32), 1), ((32, 128), 2), ((256, 512), 1), ((64, 64), 3), ((8192, 32), 1), ((32, 4096), 1),
-                                        ((64, 64), 5), ((32, 64), 12)])
+                                        ((64, 64), 5), ((32, 64), 12),
+                                        # extents 3 * 2^k (radix-3 stage): the reference's own 2-D grids are 384^2 and 1536^2 (options81:17, options84:15)
+                                        ((384, 96), 1), ((96, 1536), 2), ((384, 384), 1), ((48, 96), 3), ((384, 256), 2), ((64, 1536), 1),
+                                        ((6144, 32), 1), ((32, 6144), 1), ((192, 768), 5)])
 @pytest.mark.parametrize('h', [0.02, 5.0])
 def test_spectral_operator_vs_numpy(shape, nlig, h):
     L = tuple(n * 4.0 / 1536 for n in shape)
@@ -143,7 +146,8 @@ def test_spectral_unavailable_is_reported():
     k.close()
 
 
-@pytest.mark.parametrize('shape,nlig,h', [((64, 32), 1, 0.05), ((32, 64), 2, 0.5), ((64, 64), 1, 20.0), ((64, 32), 3, 0.3)])
+@pytest.mark.parametrize('shape,nlig,h', [((64, 32), 1, 0.05), ((32, 64), 2, 0.5), ((64, 64), 1, 20.0), ((64, 32), 3, 0.3),
+                                          ((96, 48), 1, 0.3), ((48, 96), 2, 2.0), ((96, 64), 1, 0.05)])      # 3 * 2^k extents
 @pytest.mark.parametrize('pc', [4, 2])
 def test_step_with_spectral_preconditioner_vs_oracle_lu(shape, nlig, h, pc):
     L = tuple(n * 4.0 / 1536 for n in shape)

@@ -11,7 +11,10 @@
 #include <string>
 #include <vector>
 
-#include "../ksfd_amd/csrc/stencil.hip.h"
+#define KSPEC_LAB_MINIMAL
+#include "../ksfd_amd/csrc/pointwise.hip.h"
+__device__ __forceinline__ double2 ksfd_ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+__device__ __forceinline__ double2 ksfd_ld2(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); return make_double2((double)t.x, (double)t.y); }
 #include "../ksfd_amd/csrc/spectral.hip.h"
 #include "../ksfd_amd/csrc/spectral_plan.h"
 
@@ -26,28 +29,30 @@ template <typename T> static T *up(const std::vector<T> &h)
 }
 
 struct Lab {
-    int n, F = 2, npair = 1, rb, ntiles, lg_rb, nblk_cols, thr_rows, thr_cols;
+    int n, F = 2, npair = 1, rb, ntiles, lg_rb, nblk_cols, thr_rows, thr_cols, lg_pl;
     KFFTPlan px, py;
     size_t lds_rows, lds_cols;
     long long plane;
-    float *r32; double *x, *x0; kcf *W, *W2, *twx, *twy; int *posy, *kyofpos; int4 *pairtab; float *lx, *ly;
+    float *r32; double *x, *x0; kcf *W, *W2, *twx, *twy; int *posy, *kyofpos; int4 *pairtab; float *lx, *ly; int2 *ytab; int lgw = -1;
     KSpecSym Y;
     KSpecLin ex, add;
     hipStream_t st;
     hipEvent_t ea, eb;
+    double last_min = 0.0;
 };
 
 static void lab_init(Lab &L, int n)
 {
     L.n = n; L.plane = (long long)n * n;
     if (!spec_plan(n, L.px) || !spec_plan(n, L.py)) { fprintf(stderr, "no plan for %d\n", n); exit(2); }
-    const size_t row_bytes = sizeof(kcf) * (size_t)(n + (n >> 4) + 1);
+    const size_t row_bytes = sizeof(kcf) * spec_sstride(L.px);
     int rb = (int)std::min<size_t>((160 * 1024 - 1024) / row_bytes, 16);
-    while (rb > 1 && (n % rb)) rb--;
+    while (rb & (rb - 1)) rb &= rb - 1;
+    while (rb > 1 && (n % rb)) rb >>= 1;
     while (rb > 2 && n / rb < 512) rb >>= 1;
     L.rb = rb; L.ntiles = n / rb; L.lg_rb = 0; while ((1 << L.lg_rb) < rb) L.lg_rb++;
     L.lds_rows = row_bytes * rb;
-    L.lds_cols = sizeof(kcf) * (size_t)(n + (n >> 4) + 1) * 2 * L.npair;
+    L.lds_cols = sizeof(kcf) * spec_sstride(L.py) * 2 * L.npair;
     L.thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)rb * n / 16));
     L.thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * L.npair * n / 16));
     std::vector<float> hr((size_t)L.F * L.plane);
@@ -56,12 +61,14 @@ static void lab_init(Lab &L, int n)
     for (auto &v : hr) v = (float)(rand() / (double)RAND_MAX - 0.5);
     for (auto &v : hx) v = rand() / (double)RAND_MAX - 0.5;
     L.r32 = up(hr); L.x = up(hx); L.x0 = up(hx);
-    CK(hipMalloc((void **)&L.W, sizeof(kcf) * L.npair * L.plane));
+    L.lg_pl = 0; while ((1 << L.lg_pl) < n) L.lg_pl++;              // column stride of W = 2^lg_pl (as spec_build: padded for 3 * 2^k rows)
+    CK(hipMalloc((void **)&L.W, sizeof(kcf) * L.npair * (size_t)n * ((size_t)1 << L.lg_pl)));
     CK(hipMalloc((void **)&L.W2, sizeof(kcf) * L.npair * L.plane));
-    L.twx = up(spec_twiddles(n)); L.twy = up(spec_twiddles(n));
+    L.twx = up(spec_twiddles(L.px)); L.twy = up(spec_twiddles(L.py));
     L.posy = up(spec_positions(L.py)); L.kyofpos = up(spec_inverse(spec_positions(L.py)));
     const double h = 4.0 / 1536, ih2 = 1.0 / (h * h);
     L.lx = up(spec_symbol_table(n, ih2)); L.ly = up(spec_symbol_table(n, ih2));
+    L.ytab = up(spec_partner_table(L.py, spec_symbol_table(n, ih2)));
     const std::vector<int> posx = spec_positions(L.px);
     std::vector<int4> pairs;
     for (int kx = 0; kx <= n / 2; kx++) {
@@ -84,38 +91,45 @@ static void lab_init(Lab &L, int n)
     CK(hipFuncSetAttribute((const void *)k_spec_cols<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_cols));
 }
 
+// median over 7 batches of `reps` launches (the clock the chip holds drifts by several per cent from batch to batch)
 template <typename FN> static double timeit(Lab &L, int reps, FN fn)
 {
     for (int i = 0; i < 3; i++) fn();
     CK(hipStreamSynchronize(L.st));
-    CK(hipEventRecord(L.ea, L.st));
-    for (int i = 0; i < reps; i++) fn();
-    CK(hipEventRecord(L.eb, L.st));
-    CK(hipEventSynchronize(L.eb));
-    float ms = 0.f;
-    CK(hipEventElapsedTime(&ms, L.ea, L.eb));
+    double t[7];
+    for (int b = 0; b < 7; b++) {
+        CK(hipEventRecord(L.ea, L.st));
+        for (int i = 0; i < reps; i++) fn();
+        CK(hipEventRecord(L.eb, L.st));
+        CK(hipEventSynchronize(L.eb));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, L.ea, L.eb));
+        t[b] = 1e3 * ms / reps;
+    }
     CK(hipGetLastError());
-    return 1e3 * ms / reps;
+    std::sort(t, t + 7);
+    L.last_min = t[0];
+    return t[3];
 }
 
 // baseline launches, exactly as spec_apply issues them on one rank (tile-major forward store, fused edge stages)
 static void base_fwd(Lab &L, int flags = 7, bool nofft = false)
 {
-    KFFTPlan p = L.px; p.flags = flags; if (nofft) p.nstage = 0;
+    KFFTPlan p = L.px; p.flags = flags; p.lgw = L.lgw; if (nofft) p.nstage = 0;
     hipLaunchKernelGGL(k_spec_rows_fwd<float>, dim3(L.ntiles, L.npair), dim3(L.thr_rows), L.lds_rows, L.st, p, L.n, L.rb, -L.ntiles, L.F, (const float *)L.r32, L.plane, L.W2, (const kcf *)L.twx, L.ex);
 }
 static void base_cols(Lab &L, int flags = 7, bool nofft = false)
 {
-    KFFTPlan p = L.py; p.flags = flags; if (nofft) p.nstage = 0;
-    int lg_pl = 0; while ((1 << lg_pl) < L.n) lg_pl++;
+    KFFTPlan p = L.py; p.flags = flags; p.lgw = L.lgw; if (nofft) p.nstage = 0;
+    const int lg_pl = L.lg_pl;
     hipLaunchKernelGGL(k_spec_cols<1>, dim3(L.nblk_cols), dim3(L.thr_cols), L.lds_cols, L.st, p, L.n, lg_pl, (long long)L.npair * L.n << lg_pl, L.W, (const kcf *)L.W2, L.lg_rb,
-                       (const kcf *)L.twy, (const int4 *)L.pairtab, (const int *)L.posy, (const int *)L.kyofpos, (const float *)L.lx, (const float *)L.ly, L.Y);
+                       (const kcf *)L.twy, (const int4 *)L.pairtab, (const int *)L.posy, (const int *)L.kyofpos, (const float *)L.lx, (const float *)L.ly, (const int2 *)L.ytab, L.Y);
 }
 static void base_inv(Lab &L, int flags = 7, bool nofft = false, bool with_x = true)
 {
     KFFTPlan p = L.px; p.flags = flags; if (nofft) p.nstage = 0;
     KSpecLin a = L.add; if (!with_x) a.n = 0;
-    hipLaunchKernelGGL(k_spec_rows_inv, dim3(L.ntiles, L.npair), dim3(L.thr_rows), L.lds_rows, L.st, p, L.n, L.rb, L.ntiles, L.F, (const kcf *)L.W, L.x, L.plane, (const kcf *)L.twx, a);
+    hipLaunchKernelGGL(k_spec_rows_inv, dim3(L.ntiles, L.npair), dim3(L.thr_rows), L.lds_rows, L.st, p, 1 << L.lg_pl, L.rb, L.ntiles, L.F, (const kcf *)L.W, L.x, L.plane, (const kcf *)L.twx, a);
 }
 
 static double maxdiff(Lab &L, const double *a, const double *b)
@@ -137,7 +151,7 @@ int main(int argc, char **argv)
     lab_init(L, n);
     const double N = (double)n * n, MB = 1e-6;
     printf("n=%d rb=%d lds_rows=%zu lds_cols=%zu thr_rows=%d thr_cols=%d\n", n, L.rb, L.lds_rows, L.lds_cols, L.thr_rows, L.thr_cols);
-    auto report = [&](const char *name, double us, double bytes) { printf("%-44s %8.1f us  %7.1f MB  %6.2f TB/s\n", name, us, bytes * MB, bytes / us * 1e-6); fflush(stdout); };
+    auto report = [&](const char *name, double us, double bytes) { printf("%-44s %8.1f us (min %6.1f)  %7.1f MB  %6.2f TB/s\n", name, us, L.last_min, bytes * MB, bytes / us * 1e-6); fflush(stdout); };
     // ---- baseline
     report("fwd<float> baseline", timeit(L, reps, [&] { base_fwd(L); }), 16.0 * N);
     report("fwd<float> no FFT stages", timeit(L, reps, [&] { base_fwd(L, 7, true); }), 16.0 * N);
