@@ -146,6 +146,7 @@ struct ksfd_handle {
     double mg_threshold = 75.0;      // stiffness above which pc_type 2 switches from the polynomial to multigrid
     double poly_target = 0.02;      // wanted reduction per outer iteration (picks the degree)
     float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
+    bool rhs_carry = true;          // stage vectors that enter both sides of a stage RHS are read once (k_rhs2d_fused<NL, true>); KSFD_TUNE bit 15 switches it off
     bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path; 3-D: inside the G pass + strip kernel)
     bool rhs3d_strip = true;        // 3-D RHS: G pass + z-marching strip kernel (false: generic one-thread-per-point stencil pass)
     bool poly_fp32 = true;          // Horner temporaries and coefficients of p(A) in fp32 storage (the outer A z_j stays fp64)

@@ -1001,6 +1001,8 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->zero_copy = !(use_fused & 2048) && h->hres_dev;
         h->rhs3d_strip = !(use_fused & 8192);
         h->spec_guess = !(use_fused & 16384);
+        h->rhs_carry = !(use_fused & 32768);
+        h->spec_predict = !(use_fused & 65536);
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

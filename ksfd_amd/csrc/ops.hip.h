@@ -142,9 +142,13 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         KComb C = cmb ? *cmb : KComb{};
         const long long nwaves = (long long)K.nstrips * K.nseg;
         const bool fused_norm = want_norm && nwaves <= part_capacity();
+        // the vectors added at the store are the ones the stage argument is formed from: one read serves both (k_rhs2d_fused<NL, true>)
+        bool carry = h->rhs_carry && h->P.nlig <= 2 && C.nout > 0 && C.nout == C.nin;      // (3 and 4 ligands: the delay line would cost a wave per SIMD)
+        for (int j = 0; j < C.nout && carry; j++) carry = C.yin[j] == C.yout[j];
         {
-            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + C.nout));
-            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr));
+            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + (carry ? 0 : C.nout)), vbytes(h, 2 + C.nin + C.nout));
+            if (carry) { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL, true>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr)); }
+            else { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr)); }
         }
         HIPCHK(h, hipGetLastError());
         if (fused_norm) return reduce_rows(h, 1, (int)nwaves, 0);
