@@ -39,7 +39,9 @@ struct KFFTPlan {
                                    // independent power-of-two transforms, which the stages below run as 3 * nseq sequences: in the LDS a
                                    // sequence is m sub-sequences of 2^lg elements, kspec_ss() apart (kspec_lpos)
     int radix[KSPEC_MAXSTAGE];     // DIF stage order of the power-of-two part; prod = 2^lg
-    int flags;                     // kernel variants (spec_apply): bit0/bit1 = first/last stage of k_spec_cols fused with its loads/stores, bit2 = first stage of k_spec_rows_fwd<float>
+    int flags;                     // kernel variants (spec_apply): bit0/bit1 = first/last stage of k_spec_cols fused with its loads/stores, bit2 = first stage of k_spec_rows_fwd<float>,
+                                   // bit3 = one rank: the column kernel stores its result TILE-MAJOR for the inverse row kernel (Wi[tile][pos][r], the layout
+                                   // it reads its own input in), so that kernel reads one contiguous run per tile instead of gathering 32-B pieces
     int lgw;                       // layout of the forward work array on one rank (kspec_wt_index): < 0 tile-major, else log2 of the position group
 };
 
@@ -440,12 +442,13 @@ __global__ void __launch_bounds__(1024) k_spec_rows_inv(KFFTPlan PX, int nyp, in
     const int sstride = kspec_sstride(PX);
     const kcf *Wp = W + (long long)p * nx * nyp + y0;
     const int lg_rb = 31 - __clz(rb), lg_half = PX.lg - 1;
+    const kcf *Wtile = W + ((long long)p * ntiles + y0 / rb) * nx * rb;      // (PX.flags & 8: the column kernel stored tile-major)
     for (int base = 0; base < rb * nx; base += 8 * blockDim.x) {
         kcf t[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
-            if (idx < rb * nx) { const int j = idx >> lg_rb, r = idx & (rb - 1); t[u] = Wp[(long long)j * nyp + r]; }
+            if (idx < rb * nx) { const int j = idx >> lg_rb, r = idx & (rb - 1); t[u] = (PX.flags & 8) ? Wtile[idx] : Wp[(long long)j * nyp + r]; }
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -631,6 +634,7 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
     auto colat = [&](int s, int y) {                           // y even: a float4 never straddles two pieces
         return W + (long long)(y >> lg_pl) * pstride + (((long long)(s >> 1) * nxl + ((s & 1) ? jB : jA)) << lg_pl) + (y & plmask);
     };
+    const bool tm_out = (PY.flags & 8) && lg_rb >= 1;           // result tile-major for the inverse row kernel (one rank; a float4 = two rows of one tile)
     const bool r16 = PY.m == 1 && PY.nstage > 0 && PY.radix[0] == 16 && (lg_rb < 0 || (ny >> 4) >= (1 << lg_rb));      // (a tile never holds two butterfly elements)
     if (r16 && (PY.flags & 1)) {
         // element y = i + q S0 (S0 = ny/16 >= 2^lg_rb and >= 2^lg_pl pieces are whole multiples): q moves by a constant stride
@@ -680,6 +684,12 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         const int S0 = ny >> 4;
         const bool whole = lg_pl >= PY.lg;                       // one piece per column (one rank)
         kspec_stage0_inv_to(kspec_lds, sstride, nseq, PY.lg, tw, [&](int s, int i, kcf (&c)[16]) {
+            if (tm_out) {               // y = i + q S0 -> tile (i >> lg_rb) + q (S0 >> lg_rb): a constant stride of S0 * nxl elements
+                kcf *d0 = W + (long long)(s >> 1) * nxl * ny + kspec_wt_index(-1, lg_rb, ny >> lg_rb, nxl, i >> lg_rb, (s & 1) ? jB : jA, i & ((1 << lg_rb) - 1));
+#pragma unroll
+                for (int q = 0; q < 16; q++) d0[(long long)q * S0 * nxl] = c[q];
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < 16; q++) { if (whole) colat(s, i)[q * S0] = c[q]; else *colat(s, i + q * S0) = c[q]; }
         });
@@ -690,7 +700,8 @@ __global__ void __launch_bounds__(1024) k_spec_cols(KFFTPlan PY, int nxl, int lg
         const int s = seq_of(idx), y = 2 * (idx - s * half);
         const kcf *q = kspec_lds + s * sstride;
         const kcf c0 = q[kspec_lpos(PY, y)], c1 = q[kspec_lpos(PY, y + 1)];
-        *reinterpret_cast<float4 *>(colat(s, y)) = make_float4(c0.x, c0.y, c1.x, c1.y);
+        kcf *dst = tm_out ? W + (long long)(s >> 1) * nxl * ny + kspec_wt_index(-1, lg_rb, ny >> lg_rb, nxl, y >> lg_rb, (s & 1) ? jB : jA, y & ((1 << lg_rb) - 1)) : colat(s, y);
+        *reinterpret_cast<float4 *>(dst) = make_float4(c0.x, c0.y, c1.x, c1.y);
     }
 }
 
@@ -867,19 +878,21 @@ __global__ void __launch_bounds__(1024) k_spec3_y_inv(KFFTPlan PY, int nx, int n
 
 template <int NL>
 __device__ __forceinline__ void kspec3_z_symbol(const KFFTPlan &PZ, kcf *kspec_lds, int sstride, int ne, int e0, const int4 *__restrict__ pairtab, const int *__restrict__ posz,
-                                                const int *__restrict__ kzofpos, const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, const KSpecSym &S)
+                                                const int *__restrict__ kzofpos, const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz,
+                                                const int2 *__restrict__ ztab, const KSpecSym &S)
 {
     constexpr int F = NL + 1, npair = (F + 1) / 2;
     const int nz = PZ.n, half = nz >> 1;
     for (int item = threadIdx.x; item < ne * nz; item += blockDim.x) {
         const int slot = item >> PZ.lg, mpos = item & (nz - 1);
         const int4 pt = pairtab[e0 + slot];
-        const int kz = kzofpos[mpos];
+        // ztab[pos] = (position of -kz, bits of lz[kz]), kz = the wavenumber at position pos: one coalesced load instead of the dependent
+        // chain kzofpos[pos] -> posz[-kz], lz[kz] (as in k_spec_cols); only the four self-paired columns still need kz itself
+        const int2 zt = ztab[mpos];
         const bool self = pt.w != 0;
-        if (self && kz > half) continue;                           // (A, kz) and (A, -kz) are one item
-        const int kzm = (nz - kz) & (nz - 1);
-        const int m = kspec_pad(mpos), mp = kspec_pad(posz[kzm]);
-        const float L2 = lx[pt.z & 0xffff] + ly[pt.z >> 16] + lz[kz];
+        if (self && kzofpos[mpos] > half) continue;                // (A, kz) and (A, -kz) are one item
+        const int m = kspec_pad(mpos), mp = kspec_pad(zt.x);
+        const float L2 = lx[pt.z & 0xffff] + ly[pt.z >> 16] + __int_as_float(zt.y);
         const int sa = slot * npair * 2, cb = self ? 0 : 1;
         kcf a[npair], b[npair];
 #pragma unroll
@@ -896,7 +909,7 @@ __device__ __forceinline__ void kspec3_z_symbol(const KFFTPlan &PZ, kcf *kspec_l
 template <int NPAIR_T>      // as k_spec_cols: 1, 2 or 0 = run-time number of field pairs
 __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb, long long ncol, int lg_pl, long long pstride, kcf *__restrict__ W2, const kcf *__restrict__ tw,
                                                   const int4 *__restrict__ pairtab, const int *__restrict__ posz, const int *__restrict__ kzofpos,
-                                                  const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, KSpecSym S)
+                                                  const float *__restrict__ lx, const float *__restrict__ ly, const float *__restrict__ lz, const int2 *__restrict__ ztab, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
     const int npair = NPAIR_T ? NPAIR_T : (S.nlig + 2) / 2;
@@ -924,11 +937,11 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
     });
     __syncthreads();
     kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw);
-    if (NPAIR_T == 1) kspec3_z_symbol<1>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S);
+    if (NPAIR_T == 1) kspec3_z_symbol<1>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S);
     else if (NPAIR_T == 2) {
-        if (S.nlig == 2) kspec3_z_symbol<2>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S);
-        else kspec3_z_symbol<3>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S);
-    } else { KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, S))); }
+        if (S.nlig == 2) kspec3_z_symbol<2>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S);
+        else kspec3_z_symbol<3>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S);
+    } else { KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S))); }
     __syncthreads();
     kspec_fft_inv(PZ, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {

@@ -100,7 +100,8 @@ static void spec_build3d(ksfd_handle *h)
         !spec_upload(&S.twx, spec_twiddles(S.px)) || !spec_upload(&S.twy, spec_twiddles(S.py)) ||
         !spec_upload(&S.posz, spec_positions(S.pz)) || !spec_upload(&S.kzofpos, spec_inverse(spec_positions(S.pz))) || !spec_upload(&S.pairtab, ent) ||
         !spec_upload(&S.lx, spec_symbol_table(S.px.n, h->P.inv_h2[0])) || !spec_upload(&S.ly, spec_symbol_table(S.py.n, h->P.inv_h2[1])) ||
-        !spec_upload(&S.lz, spec_symbol_table(S.pz.n, h->P.inv_h2[2]))) { hipGetLastError(); spec_free(h); return; }
+        !spec_upload(&S.lz, spec_symbol_table(S.pz.n, h->P.inv_h2[2])) ||
+        !spec_upload(&S.ytab, spec_partner_table(S.pz, spec_symbol_table(S.pz.n, h->P.inv_h2[2])))) { hipGetLastError(); spec_free(h); return; }
     // the z transforms need their own twiddle table when nz differs from ny: kept behind twy in one allocation is not worth it
     if (nzg != G.ny) {
         kcf *tz = nullptr;
@@ -302,7 +303,9 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     if (diag & 1) px_f.nstage = 0;
     if (diag & 2) py_c.nstage = 0;
     if (diag & 4) px_i.nstage = 0;
-    static const int fuse = getenv("KSFD_SPEC_FUSE") ? atoi(getenv("KSFD_SPEC_FUSE")) : 7;
+    static const int fuse_env = getenv("KSFD_SPEC_FUSE") ? atoi(getenv("KSFD_SPEC_FUSE")) : 7;
+    // bit 3 (the column kernel stores tile-major for the inverse row kernel): one rank, 2-D, plain column kernel -- set from KSFD_SPEC_FUSE as the others
+    const int fuse = (d3 || h->ring || S.cols_split || !S.tile_major) ? (fuse_env & 7) : fuse_env;
     px_f.flags = py_c.flags = px_i.flags = fuse;
     px_f.lgw = py_c.lgw = d3 ? -1 : S.lgw;
     int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
@@ -336,7 +339,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
             const long long pstride = (long long)S.npair * S.nxl * G.ny << S.lg_pl;
 #define KSPEC_Z_LAUNCH(NP) hipLaunchKernelGGL(k_spec3_z<NP>, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)S.nxl * G.ny, S.lg_pl, pstride, Wz, \
-                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, Y)
+                               (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, (const int2 *)S.ytab, Y)
             if (S.npair == 1) KSPEC_Z_LAUNCH(1); else if (S.npair == 2) KSPEC_Z_LAUNCH(2); else KSPEC_Z_LAUNCH(0);
 #undef KSPEC_Z_LAUNCH
         }
