@@ -31,7 +31,8 @@ struct MGLevel {
 // spectral preconditioner (spectral.hip.h / spectral_host.hip.h)
 struct SpecState {
     bool ok = false, means_valid = false, tile_major = false;
-    bool cols_split = false;                 // the 2*npair columns of a pair block exceed the LDS: k_spec_cols_split in two phases (spectral.hip.h)
+    int cols_split = 0;                      // k_spec_cols_split in two phases (spectral.hip.h): 1 = the 2*npair columns of a pair block exceed the LDS (one field pair per block),
+                                             // 2 = the two columns of one pair do too (columns of more than 8192 points: one column per block)
     KFFTPlan px, py, pz;
     int dim = 2, lg_cz = 0, pb = 1, nent = 0, lg_rb3 = 0;          // 3-D: z per block of the y kernels, column pairs per block / entries of the z kernel
     size_t lds_y3 = 0, lds_z3 = 0;

@@ -747,29 +747,66 @@ __device__ __forceinline__ void kspec_cols_symbol_split(const KFFTPlan &PY, kcf 
     }
 }
 
+// gridDim.z == 2: the two columns of a pair do not fit the LDS together either (columns of more than 8192 points): blockIdx.z picks ONE
+// column, and the symbol stage of phase 2 takes the partner column's values from memory as well (contiguous, walked backwards)
+template <int NL>
+__device__ __forceinline__ void kspec_cols_symbol_split1(const KFFTPlan &PY, kcf *lds, bool self, int c0, int kxA, int kxB, int p0, const kcf *__restrict__ W,
+                                                         int nxl, int lg_pl, long long pstride, int jA, int jB, const int *__restrict__ posy,
+                                                         const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly, const KSpecSym &S)
+{
+    constexpr int F = NL + 1, npair = (F + 1) / 2;
+    const int ny = PY.n, half = ny >> 1, plmask = (1 << lg_pl) - 1;
+    auto at = [&](int p, int c, int y) {
+        return W + (long long)(y >> lg_pl) * pstride + (((long long)p * nxl + (c ? jB : jA)) << lg_pl) + (y & plmask);
+    };
+    const float lxc = lx[c0 ? kxB : kxA];
+    for (int mpos = threadIdx.x; mpos < ny; mpos += blockDim.x) {
+        const int ky = kyofpos[mpos];
+        if (self && ky > half) continue;                           // a self-paired column holds both members of a pair: one item
+        const int mposp = posy[ky ? ny - ky : 0];
+        const int m = kspec_lpos(PY, mpos), mp = kspec_lpos(PY, mposp);
+        const float L2 = lxc + ly[ky];
+        kcf a[npair], b[npair];
+#pragma unroll
+        for (int p = 0; p < npair; p++) {
+            if (self) { a[p] = p == p0 ? lds[m] : *at(p, c0, mpos); b[p] = p == p0 ? lds[mp] : *at(p, c0, mposp); }
+            else if (c0 == 0) { a[p] = p == p0 ? lds[m] : *at(p, 0, mpos); b[p] = *at(p, 1, mposp); }
+            else { a[p] = *at(p, 0, mposp); b[p] = p == p0 ? lds[m] : *at(p, 1, mpos); }
+        }
+        kspec_symbol<NL>(S, L2, a, b);
+        kcf ra = a[0], rb = b[0];
+#pragma unroll
+        for (int p = 1; p < npair; p++) if (p == p0) { ra = a[p]; rb = b[p]; }
+        if (self) { lds[m] = ra; lds[mp] = rb; }
+        else lds[m] = c0 == 0 ? ra : rb;
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY, int nxl, int lg_pl, long long pstride, kcf *__restrict__ W, const kcf *__restrict__ Wt, int lg_rb,
                                                          kcf *__restrict__ Wout, const kcf *__restrict__ tw, const int4 *__restrict__ pairtab, const int *__restrict__ posy,
                                                          const int *__restrict__ kyofpos, const float *__restrict__ lx, const float *__restrict__ ly, KSpecSym S)
 {
     extern __shared__ kcf kspec_lds[];
     const int ny = PY.n, p0 = blockIdx.y;
+    const bool one = gridDim.z == 2;                            // one column per block
+    const int c0 = one ? blockIdx.z : 0, ncol = one ? 1 : 2;
     const int4 pt = pairtab[kspec_tile(blockIdx.x, gridDim.x)];
     const bool self = pt.w != 0;
     const int jA = pt.x, jB = pt.y, kxA = pt.z, kxB = self ? pt.w - 1 : pt.z;
-    const int sstride = ny + (ny >> 4) + 1;
+    const int sstride = kspec_sstride(PY);
     const int half = ny >> 1, lg_half = PY.lg - 1;
     const int plmask = (1 << lg_pl) - 1;
     auto colat = [&](kcf *base, int c, int y) {                // y even: a float4 never straddles two pieces
         return base + (long long)(y >> lg_pl) * pstride + (((long long)p0 * nxl + (c ? jB : jA)) << lg_pl) + (y & plmask);
     };
-    // both phases start by filling the LDS with the block's two columns
-    for (int base = 0; base < 2 * half; base += 8 * blockDim.x) {
+    // both phases start by filling the LDS with the block's column(s)
+    for (int base = 0; base < ncol * half; base += 8 * blockDim.x) {
         float4 t[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
-            if (idx < 2 * half) {
-                const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
+            if (idx < ncol * half) {
+                const int c = c0 + (idx >> lg_half), y = 2 * (idx & (half - 1));
                 t[u] = (phase == 1 && lg_rb >= 0)
                            ? *reinterpret_cast<const float4 *>(Wt + (long long)p0 * nxl * ny + kspec_wt_index(PY.lgw, lg_rb, ny >> lg_rb, nxl, y >> lg_rb, c ? jB : jA, y & ((1 << lg_rb) - 1)))
                            : *reinterpret_cast<const float4 *>(colat(W, c, y));
@@ -778,9 +815,9 @@ __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int idx = base + u * blockDim.x + threadIdx.x;
-            if (idx < 2 * half) {
-                const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
-                kcf *q = kspec_lds + c * sstride;
+            if (idx < ncol * half) {
+                const int cl = idx >> lg_half, y = 2 * (idx & (half - 1));
+                kcf *q = kspec_lds + cl * sstride;
                 q[kspec_pad(y)] = make_float2(t[u].x, t[u].y);
                 q[kspec_pad(y + 1)] = make_float2(t[u].z, t[u].w);
             }
@@ -788,21 +825,24 @@ __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY
     }
     __syncthreads();
     kcf *dst = W;
-    if (phase == 1) kspec_fft_fwd(PY, kspec_lds, sstride, 2, tw);
+    if (phase == 1) kspec_fft_fwd(PY, kspec_lds, sstride, ncol, tw);
     else {
-        KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol_split<NL>(PY, kspec_lds, sstride, self, kxA, kxB, p0, W, nxl, lg_pl, pstride, jA, jB, posy, kyofpos, lx, ly, S)));
+        if (one) { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol_split1<NL>(PY, kspec_lds, self, c0, kxA, kxB, p0, W, nxl, lg_pl, pstride, jA, jB, posy, kyofpos, lx, ly, S))); }
+        else { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol_split<NL>(PY, kspec_lds, sstride, self, kxA, kxB, p0, W, nxl, lg_pl, pstride, jA, jB, posy, kyofpos, lx, ly, S))); }
         __syncthreads();
-        kspec_fft_inv(PY, kspec_lds, sstride, 2, tw);
+        kspec_fft_inv(PY, kspec_lds, sstride, ncol, tw);
         dst = Wout;
     }
-    for (int idx = threadIdx.x; idx < 2 * half; idx += blockDim.x) {
-        const int c = idx >> lg_half, y = 2 * (idx & (half - 1));
-        const kcf *q = kspec_lds + c * sstride;
-        const kcf c0 = q[kspec_pad(y)], c1 = q[kspec_pad(y + 1)];
-        *reinterpret_cast<float4 *>(colat(dst, c, y)) = make_float4(c0.x, c0.y, c1.x, c1.y);
+    for (int idx = threadIdx.x; idx < ncol * half; idx += blockDim.x) {
+        const int cl = idx >> lg_half, y = 2 * (idx & (half - 1));
+        const kcf *q = kspec_lds + cl * sstride;
+        const kcf c0v = q[kspec_pad(y)], c1v = q[kspec_pad(y + 1)];
+        *reinterpret_cast<float4 *>(colat(dst, c0 + cl, y)) = make_float4(c0v.x, c0v.y, c1v.x, c1v.y);
     }
 }
+#endif // KSPEC_LAB_MINIMAL
 
+#ifndef KSPEC_LAB_MINIMAL
 // ---------------------------------------------------------------------------------------------
 // 3-D (one rank): x rows as above over the nz*ny rows (tile-major store), then
 //   k_spec3_y_fwd : one block per (pos_x, CZ consecutive z): gathers CZ columns over y from the tiles, DIF along y, stores

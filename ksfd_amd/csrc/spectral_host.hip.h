@@ -156,8 +156,13 @@ static void spec_build(ksfd_handle *h)
     S.rb = rb;
     S.lds_rows = row_bytes * rb;
     S.lds_cols = sizeof(kcf) * spec_sstride(S.py) * 2 * S.npair;
-    S.cols_split = S.lds_cols > lds_max - 1024 || (getenv("KSFD_SPEC_SPLIT") && S.npair > 1);      // (the knob: tests of the split path on small grids)
+    const int split_env = getenv("KSFD_SPEC_SPLIT") ? atoi(getenv("KSFD_SPEC_SPLIT")) : 0;        // (the knob: tests of the split paths on small grids)
+    S.cols_split = (S.lds_cols > lds_max - 1024 || (split_env == 1 && S.npair > 1) || split_env == 2) ? 1 : 0;
     if (S.cols_split) S.lds_cols = sizeof(kcf) * spec_sstride(S.py) * 2;                            // one field pair per block
+    if (S.cols_split && (S.lds_cols > lds_max - 1024 || split_env == 2)) {                          // ... one column per block (more than 8192 points)
+        S.cols_split = 2;
+        S.lds_cols = sizeof(kcf) * spec_sstride(S.py);
+    }
     if (S.lds_cols > lds_max - 1024) return;
     if (S.cols_split && !pow2) return;                               // (the two-phase column kernel is power-of-two only)
     if (hipFuncSetAttribute((const void *)k_spec_rows_fwd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_rows) != hipSuccess ||
@@ -310,7 +315,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
     px_f.lgw = py_c.lgw = d3 ? -1 : S.lgw;
     int thr_rows = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.rb * G.nx / 16));
     if (getenv("KSFD_SPEC_THRR")) thr_rows = atoi(getenv("KSFD_SPEC_THRR"));
-    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)2 * (S.cols_split ? 1 : S.npair) * ny_glob / 16));
+    int thr_cols = (int)std::min<long long>(512, std::max<long long>(128, (long long)(S.cols_split == 2 ? 1 : 2) * (S.cols_split ? 1 : S.npair) * ny_glob / 16));
     if (getenv("KSFD_SPEC_THRC")) thr_cols = atoi(getenv("KSFD_SPEC_THRC"));
     const double fn = (double)G.F * (double)G.nloc, pn = 8.0 * S.npair * (double)G.nloc;
     {
@@ -361,7 +366,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         Wc = S.W2;
     }
     {
-        Scope sc(h, KC_SPECTRAL, S.cols_split ? (4.0 + S.npair) * pn : 2.0 * pn, 0.0);      // work array in place (split: 2 + (npair + 2) passes)
+        Scope sc(h, KC_SPECTRAL, S.cols_split == 2 ? (3.0 + 2.0 * S.npair) * pn : S.cols_split ? (4.0 + S.npair) * pn : 2.0 * pn, 0.0);      // work array in place (split: 2 + (npair + 2) passes; by column: 2 + (2 npair + 1))
         const long long pstride = (long long)S.npair * S.nxl << S.lg_pl;
         int lg_rb = 0;
         while ((1 << lg_rb) < S.rb) lg_rb++;
@@ -369,7 +374,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
             // one rank: tiles (W2) -> spectrum (W) -> result (W2); slab ranks: in place in W2, then result into W as scratch
             kcf *spec = h->ring ? S.W2 : S.W, *res = h->ring ? S.W : S.W2;
             for (int phase = 1; phase <= 2; phase++)
-                hipLaunchKernelGGL(k_spec_cols_split, dim3((unsigned)S.nblk_cols, (unsigned)S.npair), dim3(thr_cols), S.lds_cols, h->st, phase, py_c, S.nxl, S.lg_pl, pstride, spec,
+                hipLaunchKernelGGL(k_spec_cols_split, dim3((unsigned)S.nblk_cols, (unsigned)S.npair, S.cols_split == 2 ? 2u : 1u), dim3(thr_cols), S.lds_cols, h->st, phase, py_c, S.nxl, S.lg_pl, pstride, spec,
                                    (const kcf *)(S.tile_major ? S.W2 : nullptr), S.tile_major ? lg_rb : -1, res, (const kcf *)S.twy,
                                    (const int4 *)S.pairtab, (const int *)S.posy, (const int *)S.kyofpos, (const float *)S.lx, (const float *)S.ly, Y);
         } else {

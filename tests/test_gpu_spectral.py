@@ -109,13 +109,16 @@ def test_spectral_operator_vs_numpy(shape, nlig, h):
     assert rel_l2(got, want) < 2e-5              # fp32 FFTs and symbol; it is a preconditioner
 
 
-@pytest.mark.parametrize('shape,nlig,forced', [((32, 8192), 2, False), ((64, 128), 2, True), ((64, 64), 3, True), ((32, 64), 5, True)])
+@pytest.mark.parametrize('shape,nlig,forced', [((32, 8192), 2, 0), ((64, 128), 2, 1), ((64, 64), 3, 1), ((32, 64), 5, 1),
+                                               # one COLUMN per block (columns of more than 8192 points do not fit the LDS in pairs): 16384 rows for real,
+                                               # forced on small grids with 1, 2 and 3 field pairs; (16384, 32): the rows of 16384 points (one row per block)
+                                               ((32, 16384), 1, 0), ((16384, 32), 1, 0), ((64, 128), 1, 2), ((128, 64), 2, 2), ((64, 64), 3, 2), ((32, 64), 5, 2)])
 def test_spectral_split_column_kernel_vs_numpy(shape, nlig, forced, monkeypatch):
     """more field pairs than the LDS holds columns for (8192 rows x 3 fields: 278 KB): the column pass runs as two launches over
     (column pair, field pair) blocks, the symbol stage reading the other field pairs' spectra from memory; KSFD_SPEC_SPLIT forces
-    that path on small grids"""
+    that path on small grids (= 2: split by column as well)"""
     if forced:
-        monkeypatch.setenv('KSFD_SPEC_SPLIT', '1')
+        monkeypatch.setenv('KSFD_SPEC_SPLIT', str(forced))
     L = tuple(n * 4.0 / 1536 for n in shape)
     cfg = _three_ligands(shape, L) if nlig == 3 else _many_ligands(2, shape, L, nlig) if nlig > 3 else ProblemConfig.standard(2, shape, L=L, nlig=nlig)
     u = _state(cfg, 3)

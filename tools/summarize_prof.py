@@ -50,6 +50,11 @@ for r in csv.DictReader(open(ks)):
     c[0] += int(r['Calls'])
     c[1] += float(r['TotalDurationNs'])
 
+# ... and per kernel (template arguments kept, argument list dropped)
+kdur = {}
+for r in csv.DictReader(open(ks)):
+    kdur[r['Name'].split('(')[0].replace('void ', '')] = (int(r['Calls']), float(r['AverageNs']) / 1e3)
+
 fe, wr = collect('fetch'), collect('write')
 kern, classes = {}, collections.defaultdict(lambda: dict(launches=0, fetch_KB=0.0, write_KB=0.0))
 for n in sorted(set(fe) | set(wr)):
@@ -58,7 +63,8 @@ for n in sorted(set(fe) | set(wr)):
     if not (nf and nw):
         continue
     kern[n] = dict(launches=nf, FETCH_SIZE_KB_avg=vf / nf, WRITE_SIZE_KB_avg=vw / nw,
-                   hbm_bytes_per_launch=(2 * vf / nf + vw / nw) * 1024)
+                   hbm_bytes_per_launch=(2 * vf / nf + vw / nw) * 1024,
+                   avg_us=kdur.get(n, (0, None))[1], trace_calls=kdur.get(n, (0, None))[0])
     c = classes[cls_of(n)]
     c['launches'] += nf
     c['fetch_KB'] += vf
