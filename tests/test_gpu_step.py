@@ -427,5 +427,7 @@ def test_default_ksp_rtol_keeps_fields_within_1e8_in_the_bench_regime():
     k.close()
     assert hs_ref.max() > 0.2, hs_ref                           # the run really reaches the regime in question
     assert rej_got == rej_ref
-    assert np.allclose(hs_got, hs_ref, rtol=1e-3, atol=0), (hs_got, hs_ref)
+    drift = float(np.abs(hs_got / hs_ref - 1.0).max())
+    print('default ksp_rtol vs 1e-12 over %d adaptive steps to T = %g: step-size drift %.2e, fields %.2e' % (len(hs_ref), T, drift, rel_l2(got, ref)))
+    assert drift < 1e-3, (hs_got, hs_ref)
     assert rel_l2(got, ref) < 1e-8
