@@ -239,6 +239,8 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * bit13 set = 3-D RHS through the generic one-thread-per-point stencil pass instead of the z-marching strip kernel;
  * bit15 set = the stage RHS kernel re-reads the stage vectors it adds at the store instead of carrying their combination along from
  * the window load; bit16 set = the spectral defect correction verifies every solve with a residual evaluation (no predicted last sweep);
+ * bit17 set = GMRES keeps the restart length it was given (default: a cycle that ends without convergence is followed by one of twice
+ * the length, up to the 30 ... 120 basis vectors ksfd_create found room for);
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

@@ -110,7 +110,8 @@ struct ksfd_handle {
     unsigned long long *pub_flag = nullptr, *pub_flag_dev = nullptr, pub_seq = 0;
     unsigned int *pub_count = nullptr;
     bool zero_copy = true;
-    int restart_alloc = 0;
+    int restart_alloc = 0;                  // basis vectors V / Zb hold (ksfd_create: 30 ... 120 by the free HBM)
+    bool restart_grow = true;               // a GMRES cycle that ends without convergence is followed by one of twice the length (KSFD_TUNE bit 17 switches it off)
     int nblk_vec = 0;                       // grid.x of the BLAS-1 kernels
     bool have_err = false;
 

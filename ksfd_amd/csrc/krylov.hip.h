@@ -176,7 +176,12 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen && !use_pc;
     if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 6) { if (stage != 0) rec_on = false; rec_reset(h); }
     const int vb = rec_on ? h->rec_vtop : 0, zb = rec_on ? h->rec_ztop : 0;
-    const int m = std::min(m_opt, h->restart_alloc - vb);
+    // Restart length.  The first cycle runs with ksp_restart (30: PETSc's default); a cycle that ends without convergence is followed by
+    // one of twice the length, up to what ksfd_create could allocate (restart_alloc, <= 120).  Restarted GMRES loses most on exactly the
+    // systems where it needs many iterations -- shift*I - J indefinite late in a run, 30-50 iterations per stage system -- and a longer
+    // basis costs little next to the V cycle and Jacobian actions of an iteration there.  Host arrays are sized for the longest cycle.
+    const int m = h->restart_alloc - vb;
+    int m_cur = std::min(m_opt, m);
     double *V = h->V + (int64_t)vb * vs;
     double *Zq = use_poly ? h->Zb + (int64_t)zb * vs : nullptr;
     int rc;
@@ -214,7 +219,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     // x0 from the recycled spaces is not written on its own: its coefficients wait (indexed by absolute slot of Zb / V) and
     // ride in the solution update of the first cycle -- one pass over x instead of two
     const bool defer_x0 = rec_on && !use_pc;
-    std::vector<double> xcoef(KSFD_MAXDOT, 0.0);
+    std::vector<double> xcoef((size_t)std::max(h->restart_alloc + 2, KSFD_MAXDOT), 0.0);
     bool x0_pending = false;
     double *const Xbase = use_poly ? h->Zb : h->V;          // slot 0 of the basis the solution is expanded in
     const int xslot0 = use_poly ? zb : vb;                  // first slot of this solve's own vectors
@@ -294,7 +299,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         g[0] = beta;
         int j = 0;
         bool done = false;
-        for (; j < m && total < maxit; j++) {
+        for (; j < m_cur && total < maxit; j++) {
             double *vj = V + (int64_t)j * vs, *w = V + (int64_t)(j + 1) * vs;
             if (use_pc) {
                 if ((rc = mg_precond(h, shift_pc, vj, h->t1)) || (rc = op_jvp_frozen_halo(h, h->t1, 1, shift, w))) return rc;
@@ -305,7 +310,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
             const int k = j + 1;
-            if (o->reserved & 1) {
+            if ((o->reserved & 1) || k > 32) {       // (the fused multi-dot + Gram-row kernel takes 32 basis vectors: longer cycles finish classically)
                 // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
                 // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
                 if ((rc = op_multidot(h, w, V, k))) return rc;
@@ -402,6 +407,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         first = false;
         if (done || total >= maxit) break;
         restarted = true;
+        if (h->restart_grow) m_cur = std::min(2 * m_cur, m);
     }
     if (!x_set) HIPCHK(h, hipMemsetAsync(x, 0, sizeof(double) * (size_t)vs, h->st));
     ls->its = total;

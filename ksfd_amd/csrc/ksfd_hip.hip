@@ -120,6 +120,8 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
     // Krylov storage is what scales with the restart length: V (m+1 vectors) + Zb (m).  Size it to the HBM that is free:
     // ~30 other full-size vectors (state, stage vectors, temporaries, coefficient planes, multigrid level 0 + coarse levels)
     // must fit first.  m = 30 on anything up to ~12k^2 x 2 fields on a 288 GB MI355X; larger grids run with a shorter restart.
+    // Round 3: where HBM is plentiful the basis may be longer than the first cycle's 30 vectors -- gmres() doubles the restart length after
+    // a cycle that did not converge (indefinite stage matrices late in a run), up to 120 and to 40 % of the free memory for V + Zb.
     h->restart_alloc = 30;
     int fit_local = 30;
     {
@@ -127,7 +129,10 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
         if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree > 0) {
             const double vecbytes = 8.0 * (double)h->vlen;
             const double room = 0.92 * (double)mfree / vecbytes - 30.0;
-            fit_local = std::min(30, (int)floor((room - 1.0) / 2.0));
+            const int fit_room = (int)floor(std::min((room - 1.0) / 2.0, 1.0e6));
+            const int fit_40 = (int)floor(std::min(0.4 * (double)mfree / vecbytes / 2.0, 1.0e6));
+            static const int cap = getenv("KSFD_RESTART_MAX") ? std::max(8, std::min(atoi(getenv("KSFD_RESTART_MAX")), 120)) : 120;
+            fit_local = std::max(std::min(std::min(cap, fit_room), fit_40), std::min(30, fit_room));
         }
     }
     if (alloc_d(h, &h->dres, 128)) CFAIL(KSFD_ENOMEM, "%s", h->err.c_str());
@@ -145,7 +150,7 @@ extern "C" int ksfd_create(const ksfd_config *cfg, const ksfd_dist *dist, ksfd_h
             CFAIL(KSFD_EHIP, "reading the agreed restart length failed");
         fit_local = (int)(-v + 0.5);
     }
-    if (fit_local < 30) {
+    if (fit_local != 30) {
         if (fit_local < 8) CFAIL(KSFD_ENOMEM, "grid too large for this device: a vector is %.2f GB, the solver needs ~47 of them (restart length that fits: %d)", 8.0 * (double)h->vlen / 1e9, fit_local);
         h->restart_alloc = fit_local;
     }
@@ -1003,6 +1008,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->spec_guess = !(use_fused & 16384);
         h->rhs_carry = !(use_fused & 32768);
         h->spec_predict = !(use_fused & 65536);
+        h->restart_grow = !(use_fused & 131072);
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

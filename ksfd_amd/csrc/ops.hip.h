@@ -445,6 +445,21 @@ static int op_lincomb(ksfd_handle *h, int nt, const double *const *x, const doub
 // d[0..k) = <w,V_i>, d[k] = <w,w>  -> h->hres
 static int op_multidot(ksfd_handle *h, const double *w, const double *V, int k)
 {
+    if (k > 32) {
+        // more basis vectors than one launch takes (restart lengths beyond 32: gmres() grows the restart when a cycle stagnates): chunks
+        // of 32, each with its own reduction; <w,w> from the last one
+        std::vector<double> acc((size_t)k + 1);
+        for (int c0 = 0; c0 < k; c0 += 32) {
+            const int kc = std::min(32, k - c0);
+            int rc = op_multidot(h, w, V + (int64_t)c0 * h->vlen, kc);
+            if (rc) return rc;
+            for (int i = 0; i < kc; i++) acc[c0 + i] = h->hres[i];
+            acc[k] = h->hres[kc];
+        }
+        if (k + 1 > 128) return fail(h, KSFD_EINVAL, "op_multidot: %d vectors exceed the result buffer", k);
+        for (int i = 0; i <= k; i++) h->hres[i] = acc[i];
+        return KSFD_OK;
+    }
     const int nb = vec2(h) ? (h->nblk_vec + 1) / 2 : h->nblk_vec;
     {
         Scope sc(h, KC_MULTIDOT, vbytes(h, k + 1));
@@ -474,6 +489,14 @@ static int op_multidot_gram(ksfd_handle *h, const double *w, const double *V, in
 
 static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const double *coef, double scale)
 {
+    if (k > 32) {                        // chunks of 32 basis vectors; the scaling rides in the last one
+        for (int c0 = 0; c0 < k; c0 += 32) {
+            const int kc = std::min(32, k - c0);
+            int rc = op_gs_update(h, w, V + (int64_t)c0 * h->vlen, kc, coef + c0, c0 + kc == k ? scale : 1.0);
+            if (rc) return rc;
+        }
+        return KSFD_OK;
+    }
     KCoef C;
     for (int i = 0; i < KSFD_MAXDOT; i++) C.h[i] = i < k ? coef[i] : 0.0;
     Scope sc(h, KC_GSUPDATE, vbytes(h, k + 2));
@@ -487,6 +510,14 @@ static int op_gs_update(ksfd_handle *h, double *w, const double *V, int k, const
 
 static int op_basis_axpy(ksfd_handle *h, double *x, const double *V, int k, const double *coef, double beta, bool want_norm = false)
 {
+    if (k > 32) {                        // chunks of 32 basis vectors: beta applies to the first, the norm comes with the last
+        for (int c0 = 0; c0 < k; c0 += 32) {
+            const int kc = std::min(32, k - c0);
+            int rc = op_basis_axpy(h, x, V + (int64_t)c0 * h->vlen, kc, coef + c0, c0 == 0 ? beta : 1.0, want_norm && c0 + kc == k);
+            if (rc) return rc;
+        }
+        return KSFD_OK;
+    }
     double *part = want_norm ? h->part : nullptr;
     KCoef C;
     int nread = 0;                                      // vectors with a zero coefficient are not loaded

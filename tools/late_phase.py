@@ -9,6 +9,8 @@ nst = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 cfg = ProblemConfig.standard(2, (384, 384), L=(1.0, 1.0), nlig=2)
 ks = klib.KSFDHip(cfg)
 ks.set_state(z['u'])
+if os.environ.get('KSFD_TUNE'):
+    ks.set_tuning(use_fused=int(os.environ['KSFD_TUNE']))
 if os.environ.get('KSFD_MG_NU'):
     ks.set_mg_params(nu=int(os.environ['KSFD_MG_NU']), ratio=float(os.environ.get('KSFD_MG_RATIO', '0')))
 if os.environ.get('KSFD_MG_POWER'):
