@@ -453,7 +453,7 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
     float *r32 = reinterpret_cast<float *>(h->Z);  // ... kept in fp32 while only the preconditioner reads it
     double rn = bn, rprev = bn;
     // fp32 residual with the norm from the store epilogue: the 2-D strip kernel, or the 3-D one when its wave count fits the partial buffer
-    const bool fused = fused_ok(h) || (strip3d_ok(h) && (long long)make_k3d(h).nblocks * (KSFD_BLOCK / KSFD_WAVE) <= part_capacity());
+    const bool fused = fused_ok(h) || (strip3d_ok(h) && (long long)make_k3d(h).nblocks * make_k3d(h).rows <= part_capacity());
     bool slow = false;
     // Predicted last sweep.  Every sweep multiplies the residual by (I - A M^-1); the four stage systems of a step share that
     // operator, so its contraction has been MEASURED by the time a solve is about to finish: rho_hat = the largest ratio

@@ -139,6 +139,7 @@ static int mg_op(ksfd_handle *h, MGLevel &L, const double *v, int mode, double s
     } else if (G.dim == 3 && h->use_fused && (G.nx % 2 == 0) && G.nx >= 16 && h->P.nlig <= 4) {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         K3D K;
+        K.rows = 4; K.sync = 0;
         K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
         K.nygrp = (int)((G.ny + 3) / 4);
         K.zseg = h->zseg;

@@ -101,15 +101,28 @@ static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
 }
 
 // launch geometry of the 3-D z-marching strip kernels
+// rows of y per block of the 3-D strip kernels (K3D).  Measured at 512^3 (bench.py --dim 3, ms per step): 4 rows 110.6, 4 rows with a
+// barrier per plane 107.8, 8 rows 111.9, 8 rows + barrier 115.5 -- so 4 rows marching in step; KSFD_ROWS3D=8 / KSFD_SYNC3D=0 for measurements
+static int rows3d(const ksfd_handle *h, long long ny)
+{
+    static const int env = getenv("KSFD_ROWS3D") ? atoi(getenv("KSFD_ROWS3D")) : 0;
+    (void)ny;
+    return (env == 8 && h->P.nlig == 1) ? 8 : 4;
+}
 static K3D make_k3d(const ksfd_handle *h)
 {
     const KGeom &G = h->G;
     K3D K;
+    K.rows = rows3d(h, G.ny);
+    {
+        static const int sync_env = getenv("KSFD_SYNC3D") ? atoi(getenv("KSFD_SYNC3D")) : 1;
+        K.sync = sync_env && (G.ny % K.rows == 0);
+    }
     K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
-    K.nygrp = (int)((G.ny + 3) / 4);
+    K.nygrp = (int)((G.ny + K.rows - 1) / K.rows);
     K.zseg = h->zseg;
     {
-        long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // blocks of 4 waves
+        long long fit = (long long)K.nstrips * K.nygrp * G.sloc / (K.rows == 8 ? 512 : 1024);      // enough blocks for 256 CUs
         if (fit < 2) fit = 2;
         if (fit < K.zseg) K.zseg = (int)fit;
     }
@@ -167,7 +180,8 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         if (C.nin) uin = h->Z;
         K3D K = make_k3d(h);
         Scope sc(h, KC_RHS, 8.0 * (2.0 * G.F + 1 + C.nout * G.F) * (double)G.nloc, vbytes(h, 2 + C.nout));
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs3d_strip<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, uin, (const double *)h->Gb, S, out, C));
+        if (K.rows == 8) hipLaunchKernelGGL((k_rhs3d_strip<1, 8>), dim3(K.nblocks), dim3(8 * KSFD_WAVE), 0, h->st, G, PP, K, uin, (const double *)h->Gb, S, out, C);
+        else NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs3d_strip<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, uin, (const double *)h->Gb, S, out, C));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -270,7 +284,8 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         }
         K3D K = make_k3d(h);
         Scope sc(h, KC_JVP, 8.0 * (2.0 * G.F + 3 + ((mode == 2 || mode == 3) ? G.F : 0)) * (double)G.nloc, alg);
-        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
+        if (K.rows == 8) hipLaunchKernelGGL((k_jvp3d_frozen<1, double, 8>), dim3(K.nblocks), dim3(8 * KSFD_WAVE), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta);
+        else NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, v, (const double *)h->dGb, mode, shift, out, yadd, alpha, beta));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -364,11 +379,12 @@ static int op_residual32(ksfd_handle *h, const double *x, double shift, const do
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dg_frozen<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, (const double *)h->coef, x, h->dGb));
         }
         K3D K = make_k3d(h);
-        const long long nwaves = (long long)K.nblocks * (KSFD_BLOCK / KSFD_WAVE);
+        const long long nwaves = (long long)K.nblocks * K.rows;
         if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");
         {
             Scope sc(h, KC_JVP, (8.0 * (2.0 * G.F + 3) + 4.0 * G.F) * (double)G.nloc, 8.0 * 4.0 * G.F * (double)G.nloc);
-            NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, x, (const double *)h->dGb, 2, shift, r32, b, 0.0, 0.0, h->part));
+            if (K.rows == 8) hipLaunchKernelGGL((k_jvp3d_frozen<1, float, 8>), dim3(K.nblocks), dim3(8 * KSFD_WAVE), 0, h->st, G, h->P, K, (const double *)h->coef, x, (const double *)h->dGb, 2, shift, r32, b, 0.0, 0.0, h->part);
+            else NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp3d_frozen<NL, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, h->P, K, (const double *)h->coef, x, (const double *)h->dGb, 2, shift, r32, b, 0.0, 0.0, h->part));
         }
         HIPCHK(h, hipGetLastError());
         return reduce_rows(h, 1, (int)nwaves, 0);

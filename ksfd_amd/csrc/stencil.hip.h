@@ -1076,8 +1076,16 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
 // with 16-B loads that hit L1/L2 (the 4 waves of a block own 4 adjacent rows).  dG is a stored plane
 // (k_dg_frozen) because the y-neighbours need it.  Traffic: dg pass 8N(3+2n) + this pass 8N(5+n+F) + F writes.
 // ---------------------------------------------------------------------------------------------
+// rows: y rows (= waves) per block.  The y-neighbour rows come through the caches, and not for free: PMC at 512^3 shows k_jvp3d_frozen
+// reading 18.3 GB per launch where its operands are 7.5 GB (136 B per point instead of 56) at 6.4 TB/s of fabric traffic.  A row of plane k is
+// loaded by its own wave three steps before its four neighbour waves ask for it, by which time an XCD's L2 (4 MB, ~1.9 MB of traffic per step)
+// has let it go.  Round 3 tried 8 rows per block (kernels templated on ROWS: the launch bound sets the register budget): slower; a barrier per
+// plane so that the four requests for a row come together: -4 %, kept (K3D.sync).  What would remove the repeated traffic is a block that
+// stages the centre plane of its rows + 4 halo rows in the LDS; not built.
 struct K3D {
-    int nstrips, nygrp, nzseg, zseg, nblocks;
+    int nstrips, nygrp, nzseg, zseg, nblocks, rows;
+    int sync;        // 1: the waves of a block march in step (a barrier per plane; needs ny % rows == 0: no wave leaves early) -- the four requests
+                     // for a row of a plane then come at the same time and three of them hit the cache
 };
 
 __device__ __forceinline__ long long ksfd_planeoff(const KGeom &G, long long k)
@@ -1093,22 +1101,22 @@ __device__ __forceinline__ long long ksfd_planeoff(const KGeom &G, long long k)
 
 // TO: storage type of `out` (float for the residual of the spectral defect correction, which only the preconditioner reads);
 // normpart != NULL: sum of squares of everything this wave stored -> normpart[blockIdx.x * 4 + wave] (fixed-order second stage)
-template <int NL, typename TO = double>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K3D S, const double *__restrict__ C,
+template <int NL, typename TO = double, int ROWS = 4>
+__global__ void __launch_bounds__(ROWS * KSFD_WAVE) k_jvp3d_frozen(KGeom G, KPhys P, K3D S, const double *__restrict__ C,
                                                              const double *__restrict__ v, const double *__restrict__ dG,
                                                              int mode, double shift, TO *__restrict__ out,
                                                              const double *__restrict__ yadd = nullptr, double alpha = 0.0, double beta = 0.0,
                                                              double *__restrict__ normpart = nullptr)
 {
     const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x >> 6;
-    if (normpart && lane == 0) normpart[(long long)blockIdx.x * (KSFD_BLOCK / KSFD_WAVE) + wv] = 0.0;      // waves that leave early contribute nothing
+    if (normpart && lane == 0) normpart[(long long)blockIdx.x * ROWS + wv] = 0.0;      // waves that leave early contribute nothing
     double nacc = 0.0;
     const long long bid = ksfd_xcd_remap(blockIdx.x, S.nblocks);
     const long long nb_valid = (long long)S.nstrips * S.nygrp * S.nzseg;
     if (bid >= nb_valid) return;
     const int strip = (int)(bid % S.nstrips);
     const long long ygrp = (bid / S.nstrips) % S.nygrp, zs = bid / ((long long)S.nstrips * S.nygrp);
-    const long long y = ygrp * (KSFD_BLOCK / KSFD_WAVE) + wv;
+    const long long y = ygrp * ROWS + wv;
     if (y >= G.ny) return;                                   // whole wave; no block barrier in this kernel
     const long long half = G.nx >> 1;
     const long long xs = 2 * ((long long)strip * half / S.nstrips), xe = 2 * ((long long)(strip + 1) * half / S.nstrips);
@@ -1154,6 +1162,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
     for (int q = -2; q <= 1; q++) { load_plane(kmap(k0 + q)); push(); }
     load_plane(kmap(k0 + 2));
     for (long long k = k0; k < k1; k++) {
+        if (S.sync) __syncthreads();
         push();
         if (k + 1 < k1) load_plane(kmap(k + 3));
         const long long kc = kmap(k);
@@ -1243,7 +1252,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp3d_frozen(KGeom G, KPhys P, K
     }
     if (normpart) {
         nacc = ksfd_wave_sum(nacc);
-        if (lane == 0) normpart[(long long)blockIdx.x * (KSFD_BLOCK / KSFD_WAVE) + wv] = nacc;
+        if (lane == 0) normpart[(long long)blockIdx.x * ROWS + wv] = nacc;
     }
 }
 
@@ -1284,8 +1293,8 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_gfield_comb(KGeom G, KPhys P, co
     }
 }
 
-template <int NL>
-__global__ void __launch_bounds__(KSFD_BLOCK) k_rhs3d_strip(KGeom G, KPhys P, K3D S, const double *__restrict__ u,
+template <int NL, int ROWS = 4>
+__global__ void __launch_bounds__(ROWS * KSFD_WAVE) k_rhs3d_strip(KGeom G, KPhys P, K3D S, const double *__restrict__ u,
                                                             const double *__restrict__ Gb, KSrc src, double *__restrict__ out,
                                                             KComb cmb)
 {
@@ -1295,7 +1304,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs3d_strip(KGeom G, KPhys P, K3
     if (bid >= nb_valid) return;
     const int strip = (int)(bid % S.nstrips);
     const long long ygrp = (bid / S.nstrips) % S.nygrp, zs = bid / ((long long)S.nstrips * S.nygrp);
-    const long long y = ygrp * (KSFD_BLOCK / KSFD_WAVE) + wv;
+    const long long y = ygrp * ROWS + wv;
     if (y >= G.ny) return;                                   // whole wave; no block barrier in this kernel
     const long long half = G.nx >> 1;
     const long long xs = 2 * ((long long)strip * half / S.nstrips), xe = 2 * ((long long)(strip + 1) * half / S.nstrips);
@@ -1340,6 +1349,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs3d_strip(KGeom G, KPhys P, K3
     for (int q = -2; q <= 1; q++) { load_plane(kmap(k0 + q)); push(); }
     load_plane(kmap(k0 + 2));
     for (long long k = k0; k < k1; k++) {
+        if (S.sync) __syncthreads();
         push();
         if (k + 1 < k1) load_plane(kmap(k + 3));
         const long long kc = kmap(k);
