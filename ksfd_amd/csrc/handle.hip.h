@@ -150,6 +150,7 @@ struct ksfd_handle {
     float *coef32 = nullptr;        // fp32 copy of the frozen coefficient planes (2-D strip path only)
     bool rhs_carry = true;          // stage vectors that enter both sides of a stage RHS are read once (k_rhs2d_fused<NL, true>); KSFD_TUNE bit 15 switches it off
     bool fuse_stage = true;         // stage-vector algebra inside the RHS kernel (2-D strip path; 3-D: inside the G pass + strip kernel)
+    bool j3l_attr_set = false, j3l_usable = false;   // k_jvp3d_lds: dynamic LDS size registered / usable (ops.hip.h: j3l_ok)
     bool rhs3d_strip = true;        // 3-D RHS: G pass + z-marching strip kernel (false: generic one-thread-per-point stencil pass)
     bool poly_fp32 = true;          // Horner temporaries and coefficients of p(A) in fp32 storage (the outer A z_j stays fp64)
 

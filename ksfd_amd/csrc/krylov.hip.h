@@ -310,7 +310,7 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 if ((rc = op_jvp_frozen_halo(h, vj, 1, shift, w))) return rc;
             } else if ((rc = halo(h, vj)) || (rc = apply_A(vj, w))) return rc;
             const int k = j + 1;
-            if ((o->reserved & 1) || k > 32) {       // (the fused multi-dot + Gram-row kernel takes 32 basis vectors: longer cycles finish classically)
+            if ((o->reserved & 1) || k > 30) {       // (the fused multi-dot + Gram-row kernel returns 2k + 1 numbers, sized for the 30 vectors of the default restart: longer cycles finish classically)
                 // classic CGS2: two Gram-Schmidt passes, each = one fused multi-dot + one fused update.
                 // (One pass alone loses orthogonality like eps*(||r0||/||r_j||)^2 and stalls near 1e-8.)
                 if ((rc = op_multidot(h, w, V, k))) return rc;
@@ -453,7 +453,7 @@ static int spec_solve(ksfd_handle *h, double shift, const double *b, double *x, 
     float *r32 = reinterpret_cast<float *>(h->Z);  // ... kept in fp32 while only the preconditioner reads it
     double rn = bn, rprev = bn;
     // fp32 residual with the norm from the store epilogue: the 2-D strip kernel, or the 3-D one when its wave count fits the partial buffer
-    const bool fused = fused_ok(h) || (strip3d_ok(h) && (long long)make_k3d(h).nblocks * make_k3d(h).rows <= part_capacity());
+    const bool fused = fused_ok(h) || (strip3d_ok(h) && (j3l_ok(h) ? (long long)make_k3d_lds(h).nblocks * KSFD_J3L_ROWS : (long long)make_k3d(h).nblocks * make_k3d(h).rows) <= part_capacity());
     bool slow = false;
     // Predicted last sweep.  Every sweep multiplies the residual by (I - A M^-1); the four stage systems of a step share that
     // operator, so its contraction has been MEASURED by the time a solve is about to finish: rho_hat = the largest ratio

@@ -132,6 +132,54 @@ static K3D make_k3d(const ksfd_handle *h)
     return K;
 }
 
+// second-generation 3-D Jacobian action (k_jvp3d_lds: y-neighbours through the LDS, dG on the fly): one or two ligands, ny a multiple of
+// its 8 rows per block; KSFD_J3L=0 keeps the first generation (dG plane pass + k_jvp3d_frozen)
+static bool j3l_ok(ksfd_handle *h)
+{
+    static const int env = getenv("KSFD_J3L") ? atoi(getenv("KSFD_J3L")) : 1;
+    if (!env || !strip3d_ok(h) || h->P.nlig > 2 || h->G.ny % KSFD_J3L_ROWS) return false;
+    if (!h->j3l_attr_set) {
+        hipError_t e = hipSuccess;
+        if (h->P.nlig == 1) {
+            e = hipFuncSetAttribute((const void *)k_jvp3d_lds<1, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ksfd_j3l_lds_bytes<1>());
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_jvp3d_lds<1, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ksfd_j3l_lds_bytes<1>());
+        } else {
+            e = hipFuncSetAttribute((const void *)k_jvp3d_lds<2, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ksfd_j3l_lds_bytes<2>());
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_jvp3d_lds<2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ksfd_j3l_lds_bytes<2>());
+        }
+        h->j3l_attr_set = true;
+        h->j3l_usable = e == hipSuccess;
+        if (e != hipSuccess) hipGetLastError();
+    }
+    return h->j3l_usable;
+}
+static K3D make_k3d_lds(const ksfd_handle *h)
+{
+    const KGeom &G = h->G;
+    K3D K;
+    K.rows = KSFD_J3L_ROWS; K.sync = 0;
+    K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+    K.nygrp = (int)(G.ny / KSFD_J3L_ROWS);
+    K.zseg = h->zseg;
+    {
+        long long fit = (long long)K.nstrips * K.nygrp * G.sloc / 1024;      // one block per CU: four rounds of blocks at least
+        if (fit < 2) fit = 2;
+        if (fit < K.zseg) K.zseg = (int)fit;
+    }
+    K.nzseg = (int)((G.sloc + K.zseg - 1) / K.zseg);
+    const long long nb3 = (long long)K.nstrips * K.nygrp * K.nzseg;
+    K.nblocks = (int)((nb3 + 7) / 8 * 8);
+    return K;
+}
+// launch of k_jvp3d_lds for 1 or 2 ligands and the storage type of the output
+template <typename TO>
+static void j3l_launch(ksfd_handle *h, const K3D &K, const double *v, int mode, double shift, TO *out, const double *yadd, double alpha, double beta, double *normpart)
+{
+    const KGeom &G = h->G;
+    if (h->P.nlig == 1) hipLaunchKernelGGL((k_jvp3d_lds<1, TO>), dim3(K.nblocks), dim3(KSFD_J3L_ROWS * KSFD_WAVE), ksfd_j3l_lds_bytes<1>(), h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta, normpart);
+    else hipLaunchKernelGGL((k_jvp3d_lds<2, TO>), dim3(K.nblocks), dim3(KSFD_J3L_ROWS * KSFD_WAVE), ksfd_j3l_lds_bytes<2>(), h->st, G, h->P, K, (const double *)h->coef, v, mode, shift, out, yadd, alpha, beta, normpart);
+}
+
 static KSrc src_of(const ksfd_handle *h, int stage)
 {
     KSrc s;
@@ -276,6 +324,10 @@ static int op_jvp_frozen(ksfd_handle *h, const double *v, int mode, double shift
         }
         HIPCHK(h, hipGetLastError());
         return want_norm ? reduce_rows(h, 1, (int)nwaves, 0) : KSFD_OK;
+    } else if (!want_norm && j3l_ok(h)) {
+        K3D K = make_k3d_lds(h);
+        Scope sc(h, KC_JVP, 8.0 * nplanes * (double)G.nloc, alg);
+        j3l_launch<double>(h, K, v, mode, shift, out, yadd, alpha, beta, nullptr);
     } else if (h->use_fused && G.dim == 3 && (G.nx % 2 == 0) && G.nx >= 4 && h->P.nlig <= 4) {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
@@ -370,6 +422,18 @@ static int jvp2d_halo_t(ksfd_handle *h, const TC *C, TV *v, int mode, double shi
 // fp64 from the store epilogue -> h->hres[0].  Single rank, strip kernels.
 static int op_residual32(ksfd_handle *h, const double *x, double shift, const double *b, float *r32)
 {
+    if (h->G.dim == 3 && j3l_ok(h)) {
+        const KGeom &G = h->G;
+        K3D K = make_k3d_lds(h);
+        const long long nwaves = (long long)K.nblocks * K.rows;
+        if (nwaves > part_capacity()) return fail(h, KSFD_EINVAL, "op_residual32: too many waves for the fused norm");
+        {
+            Scope sc(h, KC_JVP, (8.0 * (3.0 * G.F + 3 + h->P.nlig) + 4.0 * G.F) * (double)G.nloc, 8.0 * 4.0 * G.F * (double)G.nloc);
+            j3l_launch<float>(h, K, x, 2, shift, r32, b, 0.0, 0.0, h->part);
+        }
+        HIPCHK(h, hipGetLastError());
+        return reduce_rows(h, 1, (int)nwaves, 0);
+    }
     if (h->G.dim == 3) {
         // 3-D strip kernel: dG plane, then the z-marching Jacobian action in residual mode with fp32 output and the norm in its epilogue
         const KGeom &G = h->G;

@@ -1258,6 +1258,217 @@ __global__ void __launch_bounds__(ROWS * KSFD_WAVE) k_jvp3d_frozen(KGeom G, KPhy
 
 
 // ---------------------------------------------------------------------------------------------
+// 3-D frozen Jacobian action, second generation (round 3): the y-neighbours come out of the LDS, dG is formed on the fly.
+// PMC on k_jvp3d_frozen at 512^3: 18.3 GB read per launch for 7.5 GB of operands (the y-neighbour rows of the centre plane, asked for
+// through the caches three steps after their own wave loaded them, mostly come from memory again), plus a whole pass (k_dg_frozen,
+// 5.4 GB) because the y-neighbours need dG.  Here a block is R = 8 rows (waves) of one 128-column strip marching along z in step:
+//   * every wave keeps the 5-plane z windows of rho, G, v_rho, dG, v_U of ITS row in registers as before, with dG = G_rho v_rho +
+//     sum_l G_Ul v_Ul formed when a plane is loaded (G_rho, G_U read in place of the dG plane: no separate pass);
+//   * per step it publishes its centre-plane values to the LDS; waves 0..3 also load ONE halo row each (the two rows above and the two
+//     below the block: rho, G, G_rho, G_U, v -> dG) one step ahead and publish it; after one barrier every wave reads its four
+//     y-neighbour rows from the LDS (double-buffered: one barrier per step).
+// HBM per point: 8 (4 + 2 NL) own + (4 / R)(4 + 2 NL) halo + vectors of the mode, e.g. residual mode, one ligand: 64 + 24 B against
+// 136 + 40 B measured for the old pair of kernels.  x-neighbours by DPP shifts as everywhere.  ny % R == 0 (no wave leaves early).
+// ---------------------------------------------------------------------------------------------
+#define KSFD_J3L_ROWS 8
+template <int NL>
+__host__ __device__ constexpr size_t ksfd_j3l_lds_bytes() { return (size_t)2 * (KSFD_J3L_ROWS + 4) * (4 + NL) * KSFD_WAVE * sizeof(double2); }
+
+template <int NL, typename TO = double>
+__global__ void __launch_bounds__(KSFD_J3L_ROWS * KSFD_WAVE) k_jvp3d_lds(KGeom G, KPhys P, K3D S, const double *__restrict__ C,
+                                                                        const double *__restrict__ v, int mode, double shift, TO *__restrict__ out,
+                                                                        const double *__restrict__ yadd = nullptr, double alpha = 0.0, double beta = 0.0,
+                                                                        double *__restrict__ normpart = nullptr)
+{
+    constexpr int R = KSFD_J3L_ROWS, NA = 4 + NL;
+    extern __shared__ double2 j3l_lds[];                     // [2][R + 4][NA][64]
+    const int lane = threadIdx.x & (KSFD_WAVE - 1), wv = threadIdx.x >> 6;
+    if (normpart && lane == 0) normpart[(long long)blockIdx.x * R + wv] = 0.0;
+    double nacc = 0.0;
+    const long long bid = ksfd_xcd_remap(blockIdx.x, S.nblocks);
+    const long long nb_valid = (long long)S.nstrips * S.nygrp * S.nzseg;
+    if (bid >= nb_valid) return;                             // whole block
+    const int strip = (int)(bid % S.nstrips);
+    const long long ygrp = (bid / S.nstrips) % S.nygrp, zs = bid / ((long long)S.nstrips * S.nygrp);
+    const long long y0 = ygrp * R, y = y0 + wv;              // ny % R == 0: every wave has a row
+    const long long half = G.nx >> 1;
+    const long long xs = 2 * ((long long)strip * half / S.nstrips), xe = 2 * ((long long)(strip + 1) * half / S.nstrips);
+    long long c0 = (xs - 2 + 2 * lane) % G.nx;
+    if (c0 < 0) c0 += G.nx;
+    const bool store = lane >= 1 && lane <= (int)((xe - xs) >> 1);
+    const long long k0 = zs * S.zseg, k1 = k0 + S.zseg < G.sloc ? k0 + S.zseg : G.sloc;
+    const bool up = (zs & 1) == 0;
+    auto kmap = [&](long long q) { return up ? q : (k0 + k1 - 1 - q); };
+    const long long rowc = y * G.nx + c0;
+    long long hrowc = 0;                                     // waves 0..3: the halo row this wave brings in
+    if (wv < 4) {
+        long long hy = wv < 2 ? y0 - 2 + wv : y0 + R + (wv - 2);
+        hy %= G.ny;
+        if (hy < 0) hy += G.ny;
+        hrowc = hy * G.nx + c0;
+    }
+    const double *Cr = C, *Cg = C + G.plane, *Cgr = C + 2 * G.plane;
+    double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];
+    double nr[2], ng[2], nv[2], ne[2], nz[NL][2];
+    double2 hr, hg, hv, he, hz[NL];                          // halo row of the next centre plane (waves 0..3)
+    auto row_load = [&](long long o, double2 &a, double2 &b, double2 &w, double2 &e, double2 (&z)[NL]) {
+        a = ksfd_ld2(Cr + o); b = ksfd_ld2(Cg + o); w = ksfd_ld2(v + o);
+        const double2 gr = ksfd_ld2(Cgr + o);
+        e = make_double2(gr.x * w.x, gr.y * w.y);
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const double2 gu = ksfd_ld2(C + (long long)(3 + l) * G.plane + o);
+            z[l] = ksfd_ld2(v + (long long)(l + 1) * G.plane + o);
+            e.x += gu.x * z[l].x; e.y += gu.y * z[l].y;
+        }
+    };
+    auto load_plane = [&](long long k) {
+        double2 a, b, w, e, z[NL];
+        row_load(ksfd_planeoff(G, k) + rowc, a, b, w, e, z);
+        nr[0] = a.x; nr[1] = a.y; ng[0] = b.x; ng[1] = b.y; nv[0] = w.x; nv[1] = w.y; ne[0] = e.x; ne[1] = e.y;
+#pragma unroll
+        for (int l = 0; l < NL; l++) { nz[l][0] = z[l].x; nz[l][1] = z[l].y; }
+    };
+    auto push = [&]() {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                rw[s][e] = rw[s + 1][e]; gw[s][e] = gw[s + 1][e]; vw[s][e] = vw[s + 1][e]; ew[s][e] = ew[s + 1][e];
+#pragma unroll
+                for (int l = 0; l < NL; l++) zw[l][s][e] = zw[l][s + 1][e];
+            }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            rw[4][e] = nr[e]; gw[4][e] = ng[e]; vw[4][e] = nv[e]; ew[4][e] = ne[e];
+#pragma unroll
+            for (int l = 0; l < NL; l++) zw[l][4][e] = nz[l][e];
+        }
+    };
+    auto slot = [&](int buf, int row, int a) { return j3l_lds + ((long long)((buf * (R + 4) + row) * NA + a) << 6) + lane; };
+    for (int q = -2; q <= 1; q++) { load_plane(kmap(k0 + q)); push(); }
+    load_plane(kmap(k0 + 2));
+    if (wv < 4) row_load(ksfd_planeoff(G, kmap(k0)) + hrowc, hr, hg, hv, he, hz);
+    for (long long k = k0; k < k1; k++) {
+        push();
+        if (k + 1 < k1) load_plane(kmap(k + 3));
+        const long long kc = kmap(k);
+        const int buf = (int)((k - k0) & 1);
+        // centre plane of this wave's row, and of its halo row, to the LDS
+        *slot(buf, wv, 0) = make_double2(rw[2][0], rw[2][1]);
+        *slot(buf, wv, 1) = make_double2(gw[2][0], gw[2][1]);
+        *slot(buf, wv, 2) = make_double2(vw[2][0], vw[2][1]);
+        *slot(buf, wv, 3) = make_double2(ew[2][0], ew[2][1]);
+#pragma unroll
+        for (int l = 0; l < NL; l++) *slot(buf, wv, 4 + l) = make_double2(zw[l][2][0], zw[l][2][1]);
+        if (wv < 4) {
+            *slot(buf, R + wv, 0) = hr; *slot(buf, R + wv, 1) = hg; *slot(buf, R + wv, 2) = hv; *slot(buf, R + wv, 3) = he;
+#pragma unroll
+            for (int l = 0; l < NL; l++) *slot(buf, R + wv, 4 + l) = hz[l];
+            if (k + 1 < k1) row_load(ksfd_planeoff(G, kmap(k + 1)) + hrowc, hr, hg, hv, he, hz);
+        }
+        // the added vector of modes 2/3 is needed only at the store: issue its loads now
+        double2 yv_add[NL + 1];
+        if ((mode == 2 || mode == 3) && store) {
+            const long long oy = (long long)G.ng * G.inner + kc * G.nx * G.ny + rowc;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) yv_add[c] = ksfd_ld2(yadd + (long long)c * G.plane + oy);
+        }
+        __syncthreads();
+        // rows y-2, y-1, y+1, y+2 of the centre plane: LDS rows of the block, or the halo rows behind them
+        int nbr[4];
+        {
+            const int dm[4] = { -2, -1, 1, 2 };
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int rr = wv + dm[q]; nbr[q] = rr < 0 ? R + 2 + rr : (rr >= R ? R + 2 + (rr - R) : rr); }
+        }
+        const double ih0 = P.inv_h[0], ih1 = P.inv_h[1], ih2 = P.inv_h[2];
+        // one array at a time: four neighbour values from the LDS, the y- and z-derivatives, done
+        double yr1[2], yg1[2], yv1[2], ye1[2], yg2[2], ye2[2];
+        {
+            double2 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = *slot(buf, nbr[q], 0);
+            yr1[0] = KSFD_D1(t[0].x, t[1].x, t[2].x, t[3].x) * ih1; yr1[1] = KSFD_D1(t[0].y, t[1].y, t[2].y, t[3].y) * ih1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = *slot(buf, nbr[q], 1);
+            yg1[0] = KSFD_D1(t[0].x, t[1].x, t[2].x, t[3].x) * ih1; yg1[1] = KSFD_D1(t[0].y, t[1].y, t[2].y, t[3].y) * ih1;
+            yg2[0] = KSFD_D2(t[0].x, t[1].x, gw[2][0], t[2].x, t[3].x) * P.inv_h2[1]; yg2[1] = KSFD_D2(t[0].y, t[1].y, gw[2][1], t[2].y, t[3].y) * P.inv_h2[1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = *slot(buf, nbr[q], 2);
+            yv1[0] = KSFD_D1(t[0].x, t[1].x, t[2].x, t[3].x) * ih1; yv1[1] = KSFD_D1(t[0].y, t[1].y, t[2].y, t[3].y) * ih1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = *slot(buf, nbr[q], 3);
+            ye1[0] = KSFD_D1(t[0].x, t[1].x, t[2].x, t[3].x) * ih1; ye1[1] = KSFD_D1(t[0].y, t[1].y, t[2].y, t[3].y) * ih1;
+            ye2[0] = KSFD_D2(t[0].x, t[1].x, ew[2][0], t[2].x, t[3].x) * P.inv_h2[1]; ye2[1] = KSFD_D2(t[0].y, t[1].y, ew[2][1], t[2].y, t[3].y) * P.inv_h2[1];
+        }
+        const KX xr = ksfd_xnb(rw[2][0], rw[2][1]), xg = ksfd_xnb(gw[2][0], gw[2][1]);
+        const KX xv = ksfd_xnb(vw[2][0], vw[2][1]), xe_ = ksfd_xnb(ew[2][0], ew[2][1]);
+        double d1r[2], d1g[2], d1v[2], d1e[2], d2g[2], d2e[2];
+        ksfd_dx(rw[2][0], rw[2][1], xr, d1r[0], d1r[1]);
+        ksfd_dx(gw[2][0], gw[2][1], xg, d1g[0], d1g[1]);
+        ksfd_dx(vw[2][0], vw[2][1], xv, d1v[0], d1v[1]);
+        ksfd_dx(ew[2][0], ew[2][1], xe_, d1e[0], d1e[1]);
+        ksfd_dxx(gw[2][0], gw[2][1], xg, d2g[0], d2g[1]);
+        ksfd_dxx(ew[2][0], ew[2][1], xe_, d2e[0], d2e[1]);
+        double res[NL + 1][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double zr1 = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * ih2;
+            const double zg1 = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * ih2;
+            const double zv1 = KSFD_D1(vw[0][e], vw[1][e], vw[3][e], vw[4][e]) * ih2;
+            const double ze1 = KSFD_D1(ew[0][e], ew[1][e], ew[3][e], ew[4][e]) * ih2;
+            const double zg2 = KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[2];
+            const double ze2 = KSFD_D2(ew[0][e], ew[1][e], ew[2][e], ew[3][e], ew[4][e]) * P.inv_h2[2];
+            const double lapG = d2g[e] * P.inv_h2[0] + yg2[e] + zg2;
+            const double lapE = d2e[e] * P.inv_h2[0] + ye2[e] + ze2;
+            const double jr = (d1v[e] * ih0) * (d1g[e] * ih0) + (d1r[e] * ih0) * (d1e[e] * ih0) + yv1[e] * yg1[e] + yr1[e] * ye1[e] +
+                              zv1 * zg1 + zr1 * ze1 + vw[2][e] * lapG + rw[2][e] * lapE;
+            res[0][e] = mode ? shift * vw[2][e] - jr : jr;
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            double2 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = *slot(buf, nbr[q], 4 + l);
+            const KX xz = ksfd_xnb(zw[l][2][0], zw[l][2][1]);
+            double d2z[2];
+            ksfd_dxx(zw[l][2][0], zw[l][2][1], xz, d2z[0], d2z[1]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double t0 = e ? t[0].y : t[0].x, t1 = e ? t[1].y : t[1].x, t2 = e ? t[2].y : t[2].x, t3 = e ? t[3].y : t[3].x;
+                const double lap = d2z[e] * P.inv_h2[0] + KSFD_D2(t0, t1, zw[l][2][e], t2, t3) * P.inv_h2[1] +
+                                   KSFD_D2(zw[l][0][e], zw[l][1][e], zw[l][2][e], zw[l][3][e], zw[l][4][e]) * P.inv_h2[2];
+                const double ju = -P.lig_gamma[l] * zw[l][2][e] + P.lig_s[l] * vw[2][e] + P.lig_D[l] * lap;
+                res[l + 1][e] = mode ? shift * zw[l][2][e] - ju : ju;
+            }
+        }
+        if (store) {
+            const long long o = (long long)G.ng * G.inner + kc * G.nx * G.ny + rowc;
+#pragma unroll
+            for (int c = 0; c <= NL; c++) {
+                double a = res[c][0], b = res[c][1];
+                if (mode == 4) {
+                    const double c0v = c == 0 ? vw[2][0] : zw[c > 0 ? c - 1 : 0][2][0], c1v = c == 0 ? vw[2][1] : zw[c > 0 ? c - 1 : 0][2][1];
+                    a = alpha * c0v + beta * a; b = alpha * c1v + beta * b;
+                } else if (mode >= 2) {
+                    const double2 yy = yv_add[c];
+                    if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
+                }
+                if constexpr (sizeof(TO) == 4) *reinterpret_cast<float2 *>(out + (long long)c * G.plane + o) = make_float2((float)a, (float)b);
+                else ksfd_st2(out + (long long)c * G.plane + o, a, b);
+                nacc += a * a + b * b;
+            }
+        }
+    }
+    if (normpart) {
+        nacc = ksfd_wave_sum(nacc);
+        if (lane == 0) normpart[(long long)blockIdx.x * R + wv] = nacc;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // 3-D RHS, z-marching.  Two passes by design: G needs two logs and a tanh per point (fp64), and a single-pass kernel would
 // have to evaluate it for the y-halo rows of every block as well (1.5x at 8 rows per block) -- on this VALU-bound evaluation
 // that costs more than writing and re-reading one G plane.  Pass 1 (k_gfield_comb) forms the stage argument

@@ -133,7 +133,7 @@ struct CallbackTransport : Transport {
     char *a2a_send = nullptr, *a2a_recv = nullptr;   // pinned, grown on demand
     size_t a2a_cap = 0;
     double *stage = nullptr;      // pinned: [send_lo | send_hi | recv_lo | recv_hi], each F*ng*inner
-    double *hred = nullptr;       // pinned, 64 doubles
+    double *hred = nullptr;       // pinned, 128 doubles (as the handle's result buffers)
     size_t chunk = 0;
     bool init(const ksfd_dist *d, int F, long long inner)
     {
@@ -141,7 +141,7 @@ struct CallbackTransport : Transport {
         if (!ex || !ar) { err = "transport 2 needs exchange and allreduce callbacks"; return false; }
         chunk = (size_t)(F + 2) * 2 * inner;                  // F fields (+2: the 3+n coefficient planes of a coarse level fit too)
         if (hipHostMalloc((void **)&stage, sizeof(double) * chunk * 4, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&hred, sizeof(double) * 64, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return false; }
+            hipHostMalloc((void **)&hred, sizeof(double) * 128, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return false; }
         return true;
     }
     ~CallbackTransport() override { if (stage) hipHostFree(stage); if (hred) hipHostFree(hred); if (a2a_send) hipHostFree(a2a_send); if (a2a_recv) hipHostFree(a2a_recv); }
@@ -194,6 +194,7 @@ struct CallbackTransport : Transport {
     }
     int allreduce(double *dev, int n, int op, hipStream_t st) override
     {
+        if (n > 128) { err = "allreduce of more than 128 doubles"; return 1; }
         hipError_t e = hipMemcpyAsync(hred, dev, sizeof(double) * n, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { err = std::string("allreduce D2H: ") + hipGetErrorString(e); return 1; }
