@@ -85,6 +85,9 @@ struct ksfd_handle {
     double *ckpt = nullptr;                 // ksfd_checkpoint slot (allocated on first save)
     double *bstore = nullptr;               // right-hand sides of stages 0..2 of the current step (initial guesses of the spectral solves)
     bool spec_guess = true;
+    // earlier stages a stage guess is built from (the most recent ones).  Measured on the pinned window at 4096^2: 3 vectors 9.80 ms per step,
+    // 2 vectors 9.67 (same sweep counts, two full-vector reads and a multi-dot operand less for stage 4), 1 vector 9.75 (one more sweep)
+    int guess_max = getenv("KSFD_GUESS_MAX") ? std::max(1, std::min(atoi(getenv("KSFD_GUESS_MAX")), 3)) : 2;
     bool spec_predict = true;               // predicted last sweep of the defect correction (spec_solve)
     long long n_predicted = 0;              // ... how many solves ended that way
     long long n_residual = 0;               // true residuals evaluated by the spectral defect correction

@@ -737,26 +737,29 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                         gb[0][0] = bnorm2;
                     }
                     else {
-                        // <b_i, b_j> (j < i) and <b_i, b_i> in one pass; least squares on the (ill-conditioned but tiny) Gram system
-                        if ((rc = op_multidot(h, bcur, h->bstore, i))) break;
-                        for (int j = 0; j < i; j++) gb[i][j] = gb[j][i] = h->hres[j];
-                        gb[i][i] = bnorm2 = h->hres[i];
+                        // <b_i, b_j> (j0 <= j < i) and <b_i, b_i> in one pass; least squares on the (ill-conditioned but tiny) Gram system.
+                        // j0 > 0 (h->guess_max): only the most recent stages enter -- every vector of the guess costs two more full-vector
+                        // reads in the first sweep (b_j in the forward row kernel, Y_j in the inverse one) and one in this multi-dot
+                        const int j0 = std::max(0, i - h->guess_max), ng = i - j0;
+                        if ((rc = op_multidot(h, bcur, h->bstore + (int64_t)j0 * vs, ng))) break;
+                        for (int j = 0; j < ng; j++) gb[i][j0 + j] = gb[j0 + j][i] = h->hres[j];
+                        gb[i][i] = bnorm2 = h->hres[ng];
                         double M[3][4];
-                        for (int a = 0; a < i; a++) { for (int c = 0; c < i; c++) M[a][c] = gb[a][c]; M[a][i] = gb[i][a]; M[a][a] *= 1.0 + 1e-13; }
-                        bool okls = true;
-                        for (int c = 0; c < i && okls; c++) {              // Gaussian elimination with partial pivoting
+                        for (int a = 0; a < ng; a++) { for (int c = 0; c < ng; c++) M[a][c] = gb[j0 + a][j0 + c]; M[a][ng] = gb[i][j0 + a]; M[a][a] *= 1.0 + 1e-13; }
+                        bool okls = ng > 0;
+                        for (int c = 0; c < ng && okls; c++) {              // Gaussian elimination with partial pivoting
                             int pv = c;
-                            for (int a = c + 1; a < i; a++) if (fabs(M[a][c]) > fabs(M[pv][c])) pv = a;
+                            for (int a = c + 1; a < ng; a++) if (fabs(M[a][c]) > fabs(M[pv][c])) pv = a;
                             if (!(fabs(M[pv][c]) > 0.0)) { okls = false; break; }
-                            for (int q = 0; q <= i; q++) std::swap(M[c][q], M[pv][q]);
-                            for (int a = c + 1; a < i; a++) { const double f = M[a][c] / M[c][c]; for (int q = c; q <= i; q++) M[a][q] -= f * M[c][q]; }
+                            for (int q = 0; q <= ng; q++) std::swap(M[c][q], M[pv][q]);
+                            for (int a = c + 1; a < ng; a++) { const double f = M[a][c] / M[c][c]; for (int q = c; q <= ng; q++) M[a][q] -= f * M[c][q]; }
                         }
                         double cf[3] = { 0, 0, 0 };
-                        for (int a = i - 1; a >= 0 && okls; a--) { double t = M[a][i]; for (int q = a + 1; q < i; q++) t -= M[a][q] * cf[q]; cf[a] = t / M[a][a]; }
+                        for (int a = ng - 1; a >= 0 && okls; a--) { double t = M[a][ng]; for (int q = a + 1; q < ng; q++) t -= M[a][q] * cf[q]; cf[a] = t / M[a][a]; }
                         double pred = gb[i][i];                                // ||b_i - sum c_j b_j||^2 = b.b - 2 c.g + c.G c
-                        for (int a = 0; a < i; a++) { pred -= 2.0 * cf[a] * gb[i][a]; for (int c = 0; c < i; c++) pred += cf[a] * cf[c] * gb[a][c]; }
+                        for (int a = 0; a < ng; a++) { pred -= 2.0 * cf[a] * gb[i][j0 + a]; for (int c = 0; c < ng; c++) pred += cf[a] * cf[c] * gb[j0 + a][j0 + c]; }
                         if (okls && pred == pred && pred < 0.09 * gb[i][i]) {
-                            for (int j = 0; j < i; j++) if (cf[j] != 0.0) { sg.Y[sg.n] = h->Y + (int64_t)j * vs; sg.b[sg.n] = h->bstore + (int64_t)j * vs; sg.c[sg.n++] = cf[j]; }
+                            for (int j = 0; j < ng; j++) if (cf[j] != 0.0) { sg.Y[sg.n] = h->Y + (int64_t)(j0 + j) * vs; sg.b[sg.n] = h->bstore + (int64_t)(j0 + j) * vs; sg.c[sg.n++] = cf[j]; }
                         }
                     }
                 }
