@@ -204,7 +204,7 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         const long long nwaves = (long long)K.nstrips * K.nseg;
         const bool fused_norm = want_norm && nwaves <= part_capacity();
         // the vectors added at the store are the ones the stage argument is formed from: one read serves both (k_rhs2d_fused<NL, true>)
-        bool carry = h->rhs_carry && h->P.nlig <= 2 && C.nout > 0 && C.nout == C.nin;      // (3 and 4 ligands: the delay line would cost a wave per SIMD)
+        bool carry = h->rhs_carry && C.nout > 0 && C.nout == C.nin;
         for (int j = 0; j < C.nout && carry; j++) carry = C.yin[j] == C.yout[j];
         {
             Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + (carry ? 0 : C.nout)), vbytes(h, 2 + C.nin + C.nout));

@@ -506,9 +506,10 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
 
 // CARRY: the vectors added at the store are the SAME Y_j the stage argument is formed from (yout[j] == yin[j], every stage of
 // RA34PW2 but the first).  Their output combination sum_j aout[j] Y_j is then formed from the values the window load has in
-// registers anyway and rides along in a four-row delay line (the row being prefetched + window slots 4, 3, 2) until its row is
-// stored -- each Y_j crosses HBM once instead of twice (the row is three rows behind by the time it is stored: 24 KB per wave
-// further on, more than a CU's share of the L2 holds): 20 -> 14 vector passes over the four RHS launches of a step.
+// registers anyway and waits in a four-row delay line until its row is stored -- each Y_j crosses HBM once instead of twice (the row
+// is three rows behind by the time it is stored: 24 KB per wave further on, more than a CU's share of the L2 holds): 20 -> 14 vector
+// passes over the four RHS launches of a step.  The delay line is a wave-private LDS ring (8 KB per wave and ligand pair): kept in
+// registers it cost a wave per SIMD and most of the gain.
 template <int NL, bool CARRY = false>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KStrips S, const double *__restrict__ u,
                                                             KSrc src, double *__restrict__ out, KComb cmb = KComb{},
@@ -522,7 +523,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
     // 5-row windows, two columns per lane: slot s <-> row (r - 2 + s)
     double rw[5][2], gw[5][2], uw[NL][5][2];
     double nr[2], nu[NL][2];                   // raw values of the row being prefetched
-    double cq[CARRY ? 4 : 1][NL + 1][2];       // CARRY: sum_j aout[j] Y_j of the prefetched row [3] and of the rows in window slots 4, 3, 2 ([2], [1], [0])
+    // CARRY: sum_j aout[j] Y_j of a row waits in a wave-private LDS ring of four rows from the load of the row until its store three rows
+    // later (in registers the 16-32 doubles cost a wave per SIMD: 178 VGPRs against 146; wave-private and in program order: no barrier)
+    __shared__ double2 cring[CARRY ? KSFD_BLOCK / KSFD_WAVE : 1][CARRY ? 4 : 1][CARRY ? NL + 1 : 1][CARRY ? KSFD_WAVE : 1];
+    const int cw = CARRY ? (threadIdx.x >> 6) : 0, cl = CARRY ? (threadIdx.x & (KSFD_WAVE - 1)) : 0;
+    int nload = 0;                             // rows loaded so far: row r of the segment is load r - r0 + 2
 
     auto load_row = [&](long long r) {
         const long long o = ksfd_rowoff(G, r) + J.c0;
@@ -533,22 +538,26 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
             double2 q = ksfd_ld2(u + (long long)(l + 1) * G.plane + o);
             nu[l][0] = q.x; nu[l][1] = q.y;
         }
-        if (CARRY) {
+        double2 co[NL + 1];
 #pragma unroll
-            for (int c = 0; c <= NL; c++) cq[CARRY ? 3 : 0][c][0] = cq[CARRY ? 3 : 0][c][1] = 0.0;
-        }
+        for (int c = 0; c <= NL; c++) co[c] = make_double2(0.0, 0.0);
         for (int j = 0; j < cmb.nin; j++) {        // wave-uniform: stage argument u + sum a_j Y_j
             const double a = cmb.ain[j], ao = CARRY ? cmb.aout[j] : 0.0;
             double2 y = ksfd_ld2(cmb.yin[j] + o);
             nr[0] += a * y.x; nr[1] += a * y.y;
-            if (CARRY) { cq[CARRY ? 3 : 0][0][0] += ao * y.x; cq[CARRY ? 3 : 0][0][1] += ao * y.y; }
+            if (CARRY) { co[0].x += ao * y.x; co[0].y += ao * y.y; }
 #pragma unroll
             for (int l = 0; l < NL; l++) {
                 double2 q = ksfd_ld2(cmb.yin[j] + (long long)(l + 1) * G.plane + o);
                 nu[l][0] += a * q.x; nu[l][1] += a * q.y;
-                if (CARRY) { cq[CARRY ? 3 : 0][l + 1][0] += ao * q.x; cq[CARRY ? 3 : 0][l + 1][1] += ao * q.y; }
+                if (CARRY) { co[l + 1].x += ao * q.x; co[l + 1].y += ao * q.y; }
             }
         }
+        if (CARRY) {
+#pragma unroll
+            for (int c = 0; c <= NL; c++) cring[cw][nload & 3][c][cl] = co[c];
+        }
+        nload++;
     };
     auto push_row = [&]() {                     // shift windows up one row, append the prefetched row
 #pragma unroll
@@ -560,12 +569,6 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
 #pragma unroll
                 for (int l = 0; l < NL; l++) uw[l][s][e] = uw[l][s + 1][e];
             }
-        }
-        if (CARRY) {
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-#pragma unroll
-                for (int c = 0; c <= NL; c++) { cq[CARRY ? s : 0][c][0] = cq[CARRY ? s + 1 : 0][c][0]; cq[CARRY ? s : 0][c][1] = cq[CARRY ? s + 1 : 0][c][1]; }
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
             for (int c = 0; c <= NL; c++) {
                 double a = res[c][0], b = res[c][1];
                 if (src.p[c]) { double2 s = ksfd_ld2(src.p[c] + pi); a += s.x; b += s.y; }
-                if (CARRY) { a += cq[0][c][0]; b += cq[0][c][1]; }
+                if (CARRY) { const double2 cc = cring[cw][(int)(r - J.r0 + 2) & 3][c][cl]; a += cc.x; b += cc.y; }
                 else for (int j = 0; j < cmb.nout; j++) {
                     const double2 y = ksfd_ld2(cmb.yout[j] + (long long)c * G.plane + o);
                     a += cmb.aout[j] * y.x; b += cmb.aout[j] * y.y;

@@ -244,3 +244,47 @@ def test_step_3d_with_spectral_solver_vs_oracle(pc):
     assert st.linear_its <= 4 * 18, st.linear_its
     assert rel_l2(k.get_state(), un) < 1e-10
     k.close()
+
+
+def test_predicted_last_sweep_is_verified_by_the_library_itself():
+    """The spectral defect correction applies the LAST sweep of a solve on the contraction measured on the earlier sweeps instead of
+    evaluating one more residual (ksp_rtol >= 1e-8).  KSFD_SPEC_VERIFY=1 makes the library evaluate that residual anyway and fail the solve
+    (KSFD_ELINEAR) if it is above the tolerance: an adaptive run of the bench problem at 1024^2 from dt0 = 1e-8 through the ramp into the
+    regime the bench measures must get through it, with most stage solves of the later steps ending on a predicted sweep -- and give the
+    fields of the same run with every solve verified (opts.reserved bit 3) to 1e-9."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from bench import build_problem
+from ksfd_amd import lib as klib
+from ksfd_amd.initial import reference_rng
+cfg = build_problem(1024, 1)
+zc = reference_rng().normal(size=(256, 256)) * 90.0
+out = []
+for flag in (0, 8):
+    k = klib.KSFDHip(cfg)
+    k.set_state_random(zc, 9000.0)
+    o = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, reserved=flag)
+    t, h, pred, res = 0.0, 1e-8, 0, 0
+    for s in range(34):
+        t, h, st, rc = k.step(t, h, o)
+        pred += st.predicted_final
+        res += st.residual_evals
+    out.append((k.get_state(), t, pred, res))
+    k.close()
+(a, ta, pa, ra), (b, tb, pb, rb) = out
+print('RESULT', pa, ra, pb, rb, abs(ta - tb) / tb, float(np.linalg.norm(a - b) / np.linalg.norm(b)))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KSFD_SPEC_VERIFY='1')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'ABOVE TOLERANCE' not in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith('RESULT')][0].split()
+    pred, res, pred_v, res_v, dt, err = int(line[1]), int(line[2]), int(line[3]), int(line[4]), float(line[5]), float(line[6])
+    assert pred >= 30 and pred_v == 0                      # predicted sweeps happened, and the flag switches them off
+    assert res < res_v                                     # ... and they are what saves residual evaluations
+    assert r.stderr.count('predicted final sweep') == pred
+    assert dt < 1e-6 and err < 1e-9
