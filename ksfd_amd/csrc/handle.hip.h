@@ -24,6 +24,10 @@ struct MGLevel {
     double *coef = nullptr;    // [rho, G, G_rho, G_U..] planes (level 0 aliases the handle's)
     float *dinv = nullptr;     // F*F planes (fp32)
     double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *Ad = nullptr, *dG = nullptr;
+    float *x32 = nullptr, *b32 = nullptr, *r32 = nullptr, *d32 = nullptr;   // level vectors of the fp32 V cycle (f32 levels only)
+    bool f32 = false;          // this level can run the fp32 cycle (2-D strip kernel, not the coarsest level)
+    double *pv = nullptr;      // power-iteration vector of Dinv*A, kept from one set-up to the next (warm start)
+    double pv_norm = 0.0;      // its norm; 0 = no vector yet
     double lam_max = 2.3;
     double ratio = 60.0;       // lambda_max/lambda_min estimate (used on the coarsest grid)
 };
@@ -179,13 +183,17 @@ struct ksfd_handle {
     int sf_dir = 0, sf_hold = 0;  // +1 doubling, -1 halving, 0 settled (and steps to wait before the next probe)
     bool sf_tried_down = false, sf_auto = true;
     double sf_prev_its = 0.0, sf_prev_floor = 0.0;
+    bool mg_fp32 = true;         // V cycle with fp32 level vectors when the solve tolerance allows (KSFD_TUNE bit 19 clears); see mg_vcycle32
+    bool mg_use32 = false;       // ... decided per step by ksfd_step (ksp_rtol >= 1e-8)
+    bool mg_graph_f32 = false;   // precision the captured coarse cycle was recorded in
+    bool mg_warm_power = true;   // power iteration of a level starts from the vector of the previous set-up (KSFD_TUNE bit 18 clears)
     bool mg_fuse = true;         // smoother algebra inside the Jacobian-action epilogues (modes 5/6)
     bool mg_ok = false;          // hierarchy exists (2-D, single rank, >= 2 levels)
     double mg_shift = -1.0;      // shift the block diagonals / eigen-bounds were built for
     bool mg_coef_valid = false;  // coarse coefficient planes match the current frozen state
     hipGraphExec_t mg_graph = nullptr;   // captured coarse part of the V cycle (levels >= 1) for mg_graph_shift/x
     double mg_graph_shift = -1.0, mg_graph_bytes = 0.0;
-    double *mg_graph_x = nullptr;
+    const void *mg_graph_x = nullptr;
     bool capturing = false, mg_use_graph = true;
     int mg_nu = 2, mg_ncoarse = 400, mg_power_its = 8;   // smoothing sweeps, cap on coarsest-grid sweeps, power iterations
     double mg_ratio = 6.0, mg_coarse_tol = 0.3;    // coarsest-grid reduction target: 0.3 is enough (tools/mg_longrun_tune.py: 24.3 -> 19.9 ms/step at 384^2, same iterations)

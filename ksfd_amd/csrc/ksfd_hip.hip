@@ -333,6 +333,7 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
         HIPCHK(h, hipMemcpyAsync(h->ckpt, h->u, sizeof(double) * (size_t)h->vlen, hipMemcpyDeviceToDevice, h->st));
         h->ckpt_memo = { h->lamJ, h->lam_age, h->lam_period, h->mg_shift_floor, h->sf_dir, h->sf_hold, h->sf_tried_down, h->sf_prev_its, h->sf_prev_floor,
                          h->nsteps, h->spec.bad_until, h->spec.backoff, h->spec.rho_step, h->spec.rho_prev };
+        for (MGLevel &L : h->mg) L.pv_norm = 0.0;       // the step after a save and the step after a restore both set the hierarchy up cold
         h->ckpt_valid = true;
         return KSFD_OK;
     }
@@ -345,6 +346,7 @@ extern "C" int ksfd_checkpoint(ksfd_handle *h, int32_t op)
     h->nsteps = m.nsteps; h->spec.bad_until = m.spec_bad_until; h->spec.backoff = m.spec_backoff; h->spec.means_valid = false;
     h->spec.rho_step = m.spec_rho_step; h->spec.rho_prev = m.spec_rho_prev;
     h->mg_coef_valid = false; h->mg_shift = -1.0; h->poly_shift = -1.0; h->have_err = false;
+    for (MGLevel &L : h->mg) L.pv_norm = 0.0;
     rec_reset(h);
     return KSFD_OK;
 }
@@ -684,6 +686,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && !(opts->reserved & 1) && stiff >= 1e-3 &&
                                (!h->ring || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
+        h->mg_use32 = opts->ksp_rtol >= 1e-8;          // fp32 level vectors inside the V cycle (mg_vcycle32); tight tolerances keep fp64
         const bool fuse_stage = (fused_ok(h) || (strip3d_ok(h) && h->rhs3d_strip)) && h->P.nlig <= 4 && h->fuse_stage;
         const int its_before = st.linear_its;
         bool spec_failed = false;
@@ -1012,6 +1015,8 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->rhs_carry = !(use_fused & 32768);
         h->spec_predict = !(use_fused & 65536);
         h->restart_grow = !(use_fused & 131072);
+        h->mg_warm_power = !(use_fused & 262144);
+        h->mg_fp32 = !(use_fused & 524288);
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

@@ -14,9 +14,11 @@
 // coarse(I,J) = sum_{a,b in -1..1} w_a w_b fine(2I+a, 2J+b), w = (1/4, 1/2, 1/4).  x is periodic; the row axis either
 // wraps (one rank) or reads the ghost rows at local index -1 / nyf (slab ranks: the fine vector's halo must be current
 // and the slab must start on an even global row).  foff/coff = offset of local row 0 inside a plane (ng*nx).
+// TF / TK: storage type of the fine / coarse vector (the V cycle runs its level vectors in fp32 when the solve tolerance allows: mg_host.hip.h)
+template <typename TF = double, typename TK = double>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_restrict2d(int nplanes, long long nxf, long long nyf, int wrap,
-                                                           const double *__restrict__ fine, long long fplane, long long foff,
-                                                           double *__restrict__ coarse, long long cplane, long long coff)
+                                                           const TF *__restrict__ fine, long long fplane, long long foff,
+                                                           TK *__restrict__ coarse, long long cplane, long long coff)
 {
     const long long nxc = nxf >> 1, nyc = nyf >> 1, nc = nxc * nyc;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -26,19 +28,20 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_restrict2d(int nplanes, long lon
         const long long im = (i0 + nxf - 1) % nxf, ip = (i0 + 1) % nxf;
         const long long jm = wrap ? (j0 + nyf - 1) % nyf : j0 - 1, jp = wrap ? (j0 + 1) % nyf : j0 + 1;
         for (int c = 0; c < nplanes; c++) {
-            const double *f = fine + (long long)c * fplane + foff;
-            const double s = 0.25 * f[i0 + nxf * j0] +
-                             0.125 * (f[im + nxf * j0] + f[ip + nxf * j0] + f[i0 + nxf * jm] + f[i0 + nxf * jp]) +
-                             0.0625 * (f[im + nxf * jm] + f[ip + nxf * jm] + f[im + nxf * jp] + f[ip + nxf * jp]);
-            coarse[(long long)c * cplane + coff + p] = s;
+            const TF *f = fine + (long long)c * fplane + foff;
+            const double s = 0.25 * (double)f[i0 + nxf * j0] +
+                             0.125 * ((double)f[im + nxf * j0] + (double)f[ip + nxf * j0] + (double)f[i0 + nxf * jm] + (double)f[i0 + nxf * jp]) +
+                             0.0625 * ((double)f[im + nxf * jm] + (double)f[ip + nxf * jm] + (double)f[im + nxf * jp] + (double)f[ip + nxf * jp]);
+            coarse[(long long)c * cplane + coff + p] = (TK)s;
         }
     }
 }
 
 // fine += P coarse (bilinear interpolation); row axis wraps or reads the coarse ghost row nyc (slab ranks)
+template <typename TK = double, typename TF = double>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long long nxf, long long nyf, int wrap,
-                                                              const double *__restrict__ coarse, long long cplane, long long coff,
-                                                              double *__restrict__ fine, long long fplane, long long foff)
+                                                              const TK *__restrict__ coarse, long long cplane, long long coff,
+                                                              TF *__restrict__ fine, long long fplane, long long foff)
 {
     const long long nxc = nxf >> 1, nyc = nyf >> 1, nf = nxf * nyf;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -48,9 +51,9 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_prolong_add2d(int nplanes, long 
         const long long I1 = (i & 1) ? (I + 1) % nxc : I;
         const long long J1 = (j & 1) ? (wrap ? (J + 1) % nyc : J + 1) : J;
         for (int c = 0; c < nplanes; c++) {
-            const double *q = coarse + (long long)c * cplane + coff;
-            const double v = 0.25 * (q[I + nxc * J] + q[I1 + nxc * J] + q[I + nxc * J1] + q[I1 + nxc * J1]);
-            fine[(long long)c * fplane + foff + p] += v;
+            const TK *q = coarse + (long long)c * cplane + coff;
+            const double v = 0.25 * ((double)q[I + nxc * J] + (double)q[I1 + nxc * J] + (double)q[I + nxc * J1] + (double)q[I1 + nxc * J1]);
+            fine[(long long)c * fplane + foff + p] = (TF)((double)fine[(long long)c * fplane + foff + p] + v);
         }
     }
 }
@@ -195,24 +198,28 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_blockdiag_inv(KGeom G, KPhys P, 
 }
 
 // z = scale * Dinv r   (and z2 = the same values when z2 != NULL: first Chebyshev sweep from a zero guess, x = d)
-template <int NL>
+// rcopy != NULL: r itself, in the storage type of z (entry of an fp32 V cycle: the fp64 right-hand side is read once)
+template <int NL, typename TR = double, typename TZ = double>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_dinv_apply(long long n, long long plane, const float *__restrict__ dinv,
-                                                           const double *__restrict__ r, double scale, double *__restrict__ z,
-                                                           double *__restrict__ z2 = nullptr)
+                                                           const TR *__restrict__ r, double scale, TZ *__restrict__ z,
+                                                           TZ *__restrict__ z2 = nullptr, TZ *__restrict__ rcopy = nullptr)
 {
     constexpr int F = NL + 1;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         double rv[F];
 #pragma unroll
-        for (int c = 0; c < F; c++) rv[c] = r[(long long)c * plane + p];
+        for (int c = 0; c < F; c++) {
+            rv[c] = (double)r[(long long)c * plane + p];
+            if (rcopy) rcopy[(long long)c * plane + p] = (TZ)rv[c];
+        }
 #pragma unroll
         for (int a = 0; a < F; a++) {
             double s = 0.0;
 #pragma unroll
             for (int c = 0; c < F; c++) s += dinv[(long long)(a * F + c) * plane + p] * rv[c];
-            z[(long long)a * plane + p] = scale * s;
-            if (z2) z2[(long long)a * plane + p] = scale * s;
+            z[(long long)a * plane + p] = (TZ)(scale * s);
+            if (z2) z2[(long long)a * plane + p] = (TZ)(scale * s);
         }
     }
 }

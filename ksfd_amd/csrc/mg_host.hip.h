@@ -11,8 +11,10 @@ static void mg_free(ksfd_handle *h)
     for (size_t l = 0; l < h->mg.size(); l++) {
         MGLevel &L = h->mg[l];
         if (L.dinv) hipFree(L.dinv);
-        double *bufs[] = { l ? L.coef : nullptr, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG };
+        double *bufs[] = { l ? L.coef : nullptr, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG, L.pv };
         for (double *b : bufs) if (b) hipFree(b);
+        float *fb[] = { L.x32, L.b32, L.r32, L.d32 };
+        for (float *b : fb) if (b) hipFree(b);
     }
     h->mg.clear();
     h->mg_ok = false;
@@ -40,8 +42,8 @@ static int mg_build(ksfd_handle *h)
         if (l == 0) L.coef = h->coef;
         else if (alloc_d(h, &L.coef, (int64_t)(3 + nl) * L.G.plane) || alloc_d(h, &L.x, L.vlen) || alloc_d(h, &L.b, L.vlen)) return KSFD_ENOMEM;
         if (hipMalloc((void **)&L.dinv, sizeof(float) * (size_t)F * F * L.G.plane) != hipSuccess || alloc_d(h, &L.r, L.vlen) || alloc_d(h, &L.d, L.vlen) ||
-            alloc_d(h, &L.Ad, L.vlen) || alloc_d(h, &L.dG, L.G.plane)) return KSFD_ENOMEM;
-        double *zero[] = { l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad };
+            alloc_d(h, &L.Ad, L.vlen) || alloc_d(h, &L.dG, L.G.plane) || alloc_d(h, &L.pv, L.vlen)) return KSFD_ENOMEM;
+        double *zero[] = { l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.pv };
         for (double *z : zero) if (z) hipMemsetAsync(z, 0, sizeof(double) * (size_t)L.vlen, h->st);
         h->mg.push_back(L);
         // next level: every rank keeps >= 4 slow units (ghost width 2 + the 4th-order star), global grid >= 8 per axis
@@ -54,6 +56,20 @@ static int mg_build(ksfd_handle *h)
     }
     h->mg_ok = h->mg.size() >= 2;
     if (h->ring) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
+    // fp32 level vectors (mg_vcycle32): one rank, 2-D, levels the strip kernel serves, never the coarsest one (its many Chebyshev sweeps
+    // stay in fp64 with the kernels they have)
+    if (h->mg_ok && dim == 2 && !h->ring && h->use_fused && nl <= 4) {
+        for (size_t l = 0; l + 1 < h->mg.size(); l++) {
+            MGLevel &L = h->mg[l];
+            if ((L.G.nx % 2) || L.G.nx < 16) break;
+            const size_t nb = sizeof(float) * (size_t)L.vlen;
+            if (hipMalloc((void **)&L.x32, nb) != hipSuccess || hipMalloc((void **)&L.b32, nb) != hipSuccess ||
+                hipMalloc((void **)&L.r32, nb) != hipSuccess || hipMalloc((void **)&L.d32, nb) != hipSuccess) { (void)hipGetLastError(); break; }
+            float *zero[] = { L.x32, L.b32, L.r32, L.d32 };
+            for (float *z : zero) hipMemsetAsync(z, 0, nb, h->st);
+            L.f32 = true;
+        }
+    }
     return KSFD_OK;
 }
 
@@ -68,7 +84,7 @@ static void mg_launch_restrict(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np,
         hipLaunchKernelGGL(k_restrict3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
                            fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
     else
-        hipLaunchKernelGGL(k_restrict2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
+        hipLaunchKernelGGL((k_restrict2d<double, double>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
                            fine, Lf.G.plane, Lf.kv.off, coarse, Lc.G.plane, Lc.kv.off);
 }
 static void mg_launch_prolong(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, const double *coarse, double *fine)
@@ -81,7 +97,7 @@ static void mg_launch_prolong(ksfd_handle *h, MGLevel &Lf, MGLevel &Lc, int np, 
         hipLaunchKernelGGL(k_prolong_add3d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.ny, Lf.G.sloc, Lf.G.wrap_slow,
                            coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
     else
-        hipLaunchKernelGGL(k_prolong_add2d, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
+        hipLaunchKernelGGL((k_prolong_add2d<double, double>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
                            coarse, Lc.G.plane, Lc.kv.off, fine, Lf.G.plane, Lf.kv.off);
 }
 
@@ -211,25 +227,34 @@ static int mg_setup_shift(ksfd_handle *h, double shift)
             NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_blockdiag_inv<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G, L.P, (const double *)L.coef, shift, L.dinv));
         }
         HIPCHK(h, hipGetLastError());
-        // power iteration on Dinv*A: v in L.d, A v in L.Ad, Dinv A v in L.r
-        hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)L.vlen, L.d);
-        double nv = 1.0, lam = 2.0;
-        if ((rc = mg_norm(h, L, L.d, &nv))) return rc;
-        for (int it = 0; it < h->mg_power_its; it++) {
-            if ((rc = mg_op(h, L, L.d, 1, shift, L.Ad, nullptr))) return rc;
+        // power iteration on Dinv*A: v and w = Dinv A v / |v| alternate between L.pv and L.r, A v in L.Ad.  The vector is kept
+        // from one set-up to the next (L.pv): the shift and the frozen state move a little from step to step and the dominant
+        // vector with them, so a warm start needs 2-3 iterations where the cold one from a hash fill takes mg_power_its
+        // (4096^2 x 3 fields: 9.4 -> 2.9 ms of set-up per step).
+        double *v = L.pv, *w = L.r;
+        double nv = L.pv_norm, lam = 2.0, lam_prev = 0.0;
+        const bool warm = nv > 0.0 && h->mg_warm_power;
+        if (!warm) {
+            hipLaunchKernelGGL(k_hash_fill, dim3(nb), dim3(KSFD_BLOCK), 0, h->st, (long long)L.vlen, v);
+            if ((rc = mg_norm(h, L, v, &nv))) return rc;
+        }
+        const int its = warm ? std::min(h->mg_power_its, 3) : h->mg_power_its;
+        for (int it = 0; it < its; it++) {
+            if (!(nv > 0.0) || nv != nv) break;
+            if ((rc = mg_op(h, L, v, 1, shift, L.Ad, nullptr))) return rc;
             {
-                Scope sc(h, KC_MG, 8.0 * (2 * F + F * F) * L.G.nloc);
-                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0, L.r + L.kv.off));
+                Scope sc(h, KC_MG, 8.0 * (2 * F + 0.5 * F * F) * L.G.nloc);
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0 / nv, w + L.kv.off));
             }
             double nw;
-            if ((rc = mg_norm(h, L, L.r, &nw))) return rc;
-            if (!(nw > 0.0) || !(nv > 0.0)) break;
-            lam = nw / nv;
-            // v <- w / |w|
-            Scope sc(h, KC_MG, 16.0 * L.vlen);
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + L.kv.off), (const double *)(L.Ad + L.kv.off), 1.0 / nw, L.d + L.kv.off));
-            nv = 1.0;
+            if ((rc = mg_norm(h, L, w, &nw))) return rc;
+            if (!(nw > 0.0)) break;
+            lam_prev = lam; lam = nw;                              // |Dinv A v| / |v|
+            std::swap(v, w); nv = nw;
+            if (warm && it >= 1 && fabs(lam - lam_prev) <= 0.01 * lam) break;
         }
+        if (v != L.pv) HIPCHK(h, hipMemcpyAsync(L.pv, v, sizeof(double) * (size_t)L.vlen, hipMemcpyDeviceToDevice, h->st));
+        L.pv_norm = (nv > 0.0 && nv == nv) ? nv : 0.0;
         L.lam_max = 1.15 * lam;
         if (l + 1 == h->mg.size()) {
             int nbr = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 256);
@@ -338,6 +363,37 @@ static int mg_coarse_correction(ksfd_handle *h, size_t l, double shift, double *
     return KSFD_OK;
 }
 
+// everything below level 0 touches only fixed buffers: capture it once per shift into a hipGraph and replay it (a V cycle has ~15
+// launches per level; on small grids they are pure launch latency).  body = the coarse-grid correction of level 0 in the precision in use.
+template <typename Body>
+static int mg_coarse_graph(ksfd_handle *h, double shift, const void *xkey, bool f32, Body body)
+{
+    int rc;
+    if (!h->mg_graph || h->mg_graph_shift != shift || h->mg_graph_x != xkey || h->mg_graph_f32 != f32) {
+        if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
+        hipGraph_t g = nullptr;
+        const double b0 = h->bytes_acc;
+        HIPCHK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+        h->capturing = true;
+        rc = body();
+        h->capturing = false;
+        hipError_t e = hipStreamEndCapture(h->st, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return fail(h, KSFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&h->mg_graph, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { h->mg_graph = nullptr; return fail(h, KSFD_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        h->mg_graph_bytes = h->bytes_acc - b0;
+        h->bytes_acc = b0;
+        h->mg_graph_shift = shift;
+        h->mg_graph_x = xkey;
+        h->mg_graph_f32 = f32;
+    }
+    Scope sc(h, KC_MG, h->mg_graph_bytes);
+    HIPCHK(h, hipGraphLaunch(h->mg_graph, h->st));
+    return KSFD_OK;
+}
+
 static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, double *x)
 {
     int rc;
@@ -351,33 +407,114 @@ static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, do
     if ((rc = mg_smooth(h, L, shift, b, x, h->mg_nu, true, h->mg_ratio))) return rc;
     if ((rc = mg_op(h, L, x, 2, shift, L.r, b))) return rc;
     if (l == 0 && h->mg_use_graph && !h->capturing) {
-        // everything below level 0 touches only fixed buffers: capture it once per shift into a hipGraph and
-        // replay it (a V cycle has ~15 launches per level; on small grids they are pure launch latency)
-        if (!h->mg_graph || h->mg_graph_shift != shift || h->mg_graph_x != x) {
-            if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; }
-            hipGraph_t g = nullptr;
-            const double b0 = h->bytes_acc;
-            HIPCHK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
-            h->capturing = true;
-            rc = mg_coarse_correction(h, 0, shift, x);
-            h->capturing = false;
-            hipError_t e = hipStreamEndCapture(h->st, &g);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess || !g) return fail(h, KSFD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            e = hipGraphInstantiate(&h->mg_graph, g, nullptr, nullptr, 0);
-            hipGraphDestroy(g);
-            if (e != hipSuccess) { h->mg_graph = nullptr; return fail(h, KSFD_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-            h->mg_graph_bytes = h->bytes_acc - b0;
-            h->bytes_acc = b0;
-            h->mg_graph_shift = shift;
-            h->mg_graph_x = x;
-        }
-        {
-            Scope sc(h, KC_MG, h->mg_graph_bytes);
-            HIPCHK(h, hipGraphLaunch(h->mg_graph, h->st));
-        }
+        if ((rc = mg_coarse_graph(h, shift, x, false, [&]() { return mg_coarse_correction(h, 0, shift, x); }))) return rc;
     } else if ((rc = mg_coarse_correction(h, l, shift, x))) return rc;
     return mg_smooth(h, L, shift, b, x, h->mg_nu, false, h->mg_ratio);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same V(2,2) cycle with fp32 LEVEL VECTORS (x, b, r, d of every f32 level; the arithmetic inside the kernels stays fp64).
+// A V cycle is a preconditioner: GMRES sees the true fp64 residual of the real system whatever the cycle returns, and the cycle is
+// bandwidth-bound -- at 4096^2 x 3 fields an iteration moves ~82 planes of 134 MB through level 0 alone, two thirds of them level
+// vectors.  Used when the step's ksp_rtol >= 1e-8 (ksfd_step; the parity tests at 1e-11 keep the fp64 cycle), one rank, 2-D,
+// V(2,2) with the fused smoother.  The fp64 right-hand side is read once (k_dinv_apply leaves its fp32 copy), the last smoothing
+// kernel writes the result in fp64 (KSmoothT::x64); levels below the last f32 one run the fp64 code above, the transfer kernels
+// convert at that border.
+// ------------------------------------------------------------------------------------------------
+static int mg_op32(ksfd_handle *h, MGLevel &L, const float *v, int mode, double shift, float *out, const float *yadd, const KSmoothT<float> *sm)
+{
+    const KGeom &G = L.G;
+    const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
+    const float *c32 = (&L == &h->mg[0] && h->poly_fp32) ? h->coef32 : nullptr;
+    // planes moved (in units of 8 B per point): coefficients, v, per mode: 2: yadd + out; 5: yadd, Dinv, r, d; 6: Dinv, rr, x in and out
+    const double by = ((c32 ? 4.0 : 8.0) * (3 + h->P.nlig) + 4.0 * G.F + (mode == 2 ? 8.0 * G.F : 12.0 * G.F + 4.0 * G.F * G.F + ((sm && sm->x64) ? 4.0 * G.F : 0.0))) * (double)G.nloc;
+    KStrips K;
+    K.nstrips = (int)((G.nx + KSFD_STRIP_OUT - 1) / KSFD_STRIP_OUT);
+    K.yseg = h->yseg_jvp;
+    {
+        long long fit = (long long)K.nstrips * G.sloc / 4096;
+        if (fit < 2) fit = 2;
+        if (fit < K.yseg) K.yseg = (int)fit;
+    }
+    K.nseg = (int)((G.sloc + K.yseg - 1) / K.yseg);
+    K.seg0 = 0; K.seg_stride = 1;
+    long long nb = ((long long)K.nstrips * K.nseg + 3) / 4;
+    K.nblocks = (int)((nb + 7) / 8 * 8);
+    const KSmoothT<float> S = sm ? *sm : KSmoothT<float>{};
+    Scope sc(h, cls, by);
+    if (sm && c32) {
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, float, float, float, float, 1, true, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, c32, v, mode, shift, out, yadd, 0.0, 0.0, S));
+    } else if (sm) {
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, double, float, float, float, 1, true, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd, 0.0, 0.0, S));
+    } else if (c32) {
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, float, float, float, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, c32, v, mode, shift, out, yadd));
+    } else {
+        NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_jvp2d_frozen<NL, double, float, float, float>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, L.P, K, (const double *)L.coef, v, mode, shift, out, yadd));
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+static int mg_vcycle32(ksfd_handle *h, size_t l, double shift, const double *b64, double *x64);
+
+// coarse-grid correction of an f32 level: restrict r32, recurse in the precision of the next level, prolong-add into x32
+static int mg_coarse_correction32(ksfd_handle *h, size_t l, double shift)
+{
+    int rc;
+    MGLevel &L = h->mg[l], &Lc = h->mg[l + 1];
+    const int F = L.G.F;
+    const int nbr = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    const int nbp = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    {
+        Scope sc(h, KC_MG, F * (4.0 * L.G.nloc + (Lc.f32 ? 4.0 : 8.0) * Lc.G.nloc));
+        if (Lc.f32) hipLaunchKernelGGL((k_restrict2d<float, float>), dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, F, L.G.nx, L.G.sloc, L.G.wrap_slow, (const float *)L.r32, L.G.plane, L.kv.off, Lc.b32, Lc.G.plane, Lc.kv.off);
+        else hipLaunchKernelGGL((k_restrict2d<float, double>), dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, F, L.G.nx, L.G.sloc, L.G.wrap_slow, (const float *)L.r32, L.G.plane, L.kv.off, Lc.b, Lc.G.plane, Lc.kv.off);
+    }
+    if (Lc.f32) rc = mg_vcycle32(h, l + 1, shift, nullptr, nullptr);
+    else rc = mg_vcycle(h, l + 1, shift, Lc.b, Lc.x);
+    if (rc) return rc;
+    {
+        Scope sc(h, KC_MG, F * (8.0 * L.G.nloc + (Lc.f32 ? 4.0 : 8.0) * Lc.G.nloc));
+        if (Lc.f32) hipLaunchKernelGGL((k_prolong_add2d<float, float>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, F, L.G.nx, L.G.sloc, L.G.wrap_slow, (const float *)Lc.x32, Lc.G.plane, Lc.kv.off, L.x32, L.G.plane, L.kv.off);
+        else hipLaunchKernelGGL((k_prolong_add2d<double, float>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, F, L.G.nx, L.G.sloc, L.G.wrap_slow, (const double *)Lc.x, Lc.G.plane, Lc.kv.off, L.x32, L.G.plane, L.kv.off);
+    }
+    HIPCHK(h, hipGetLastError());
+    return KSFD_OK;
+}
+
+// level l of the fp32 cycle.  l = 0: right-hand side b64 and result x64 in fp64 (the caller's vectors); l > 0: L.b32 -> L.x32.
+static int mg_vcycle32(ksfd_handle *h, size_t l, double shift, const double *b64, double *x64)
+{
+    int rc;
+    MGLevel &L = h->mg[l];
+    const int F = L.G.F;
+    const int nb = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    const double lmax = L.lam_max, lmin = lmax / h->mg_ratio;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sig1 = theta / delta;
+    const double rho0 = 1.0 / sig1, rhon = 1.0 / (2.0 * sig1 - rho0);
+    const long long off = L.kv.off;
+    KSmoothT<float> S = KSmoothT<float>{};
+    S.dinv = L.dinv; S.x = L.x32; S.c1 = rhon * rho0; S.c2 = 2.0 * rhon / delta;
+    // pre-smoothing from a zero guess: d0 = Dinv b / theta, x = d0 (+ the fp32 copy of b on level 0); then x += d1 in the epilogue of A d0
+    {
+        Scope sc(h, KC_MG, ((b64 ? 8.0 + 4.0 : 4.0) * F + 8.0 * F + 4.0 * F * F) * (double)L.G.nloc);
+        if (b64) {
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL, double, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), b64 + off, 1.0 / theta, L.d32 + off, L.x32 + off, L.b32 + off));
+        } else {
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL, float, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), (const float *)(L.b32 + off), 1.0 / theta, L.d32 + off, L.x32 + off));
+        }
+    }
+    S.rr = L.b32; S.x_has_d = 1;
+    if ((rc = mg_op32(h, L, L.d32, 6, shift, nullptr, nullptr, &S))) return rc;
+    if ((rc = mg_op32(h, L, L.x32, 2, shift, L.r32, L.b32, nullptr))) return rc;
+    if (l == 0 && h->mg_use_graph && !h->capturing) {
+        if ((rc = mg_coarse_graph(h, shift, L.x32, true, [&]() { return mg_coarse_correction32(h, 0, shift); }))) return rc;
+    } else if ((rc = mg_coarse_correction32(h, l, shift))) return rc;
+    // post-smoothing: r = b - A x and d0 = Dinv r / theta in one launch, x += d0 + d1 in the next (level 0: into the caller's fp64 vector)
+    S.out2 = L.d32; S.scale = 1.0 / theta;
+    if ((rc = mg_op32(h, L, L.x32, 5, shift, L.r32, L.b32, &S))) return rc;
+    S.rr = L.r32; S.x_has_d = 0; S.x64 = x64;
+    return mg_op32(h, L, L.d32, 6, shift, nullptr, nullptr, &S);
 }
 
 // out = M^-1 in  (one V cycle)
@@ -386,5 +523,6 @@ static int mg_precond(ksfd_handle *h, double shift, const double *in, double *ou
     int rc;
     if (!h->mg_coef_valid && (rc = mg_restrict_coefs(h))) return rc;
     if (h->mg_shift != shift && (rc = mg_setup_shift(h, shift))) return rc;
+    if (h->mg_use32 && h->mg_fp32 && h->mg[0].f32 && h->mg_nu == 2 && mg_can_fuse(h, h->mg[0])) return mg_vcycle32(h, 0, shift, in, out);
     return mg_vcycle(h, 0, shift, in, out);
 }

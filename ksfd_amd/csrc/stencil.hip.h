@@ -30,13 +30,16 @@ struct KComb {
 //   5:  r = yadd - A v  -> out ;  d = scale * Dinv r -> out2                (residual + first Chebyshev direction)
 //   6:  x += (x_has_d ? 0 : d) + c1*d + c2 * Dinv (rr - A d),  v = d        (k_cheb_last without the A d round trip)
 // Dinv: F*F planes of the inverse point-block diagonal (row-major), all vectors in the level's ghosted layout.
-struct KSmooth {
+template <typename TS = double>
+struct KSmoothT {
     const float *dinv;
-    const double *rr;
-    double *x, *out2;
+    const TS *rr;
+    TS *x, *out2;
     double c1, c2, scale;
     int x_has_d;
+    double *x64;         // mode 6: the updated x goes HERE in fp64 instead of back to x (last sweep of an fp32 V cycle: the result in the caller's precision)
 };
+typedef KSmoothT<double> KSmooth;
 
 // ---------------------------------------------------------------------------------------------
 // generic family
@@ -896,11 +899,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_dg_frozen(KGeom G, const double 
 // Also measured and dropped: rotating the 5-row windows through a five-fold unrolled row loop (no register moves, same
 // 196 VGPR): 6 % SLOWER (0.198 -> 0.210 ms), the five copies of the body cost more in instruction fetch than the ~100
 // v_mov per row they save.
-template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double, int PF = 1, bool SMOOTH = false>
+template <int NL, typename TC = double, typename TV = double, typename TY = double, typename TO = double, int PF = 1, bool SMOOTH = false, typename TS = double>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, KStrips S, const TC *__restrict__ C,
                                                              const TV *__restrict__ v, int mode, double shift,
                                                              TO *__restrict__ out, const TY *__restrict__ yadd = nullptr,
-                                                             double alpha = 0.0, double beta = 0.0, KSmooth sm = KSmooth{},
+                                                             double alpha = 0.0, double beta = 0.0, KSmoothT<TS> sm = KSmoothT<TS>{},
                                                              double *__restrict__ normpart = nullptr)
 {
     // normpart != NULL (modes 0-4): ||out||^2 partials per wave, see k_rhs2d_fused
@@ -1035,8 +1038,10 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                             ksfd_st2(sm.out2 + (long long)a * G.plane + o, sm.scale * s0, sm.scale * s1);
                         } else {
                             const double d0 = a == 0 ? vw[2][0] : zw[a > 0 ? a - 1 : 0][2][0], d1 = a == 0 ? vw[2][1] : zw[a > 0 ? a - 1 : 0][2][1];
-                            ksfd_st2(sm.x + (long long)a * G.plane + o, xs_[a].x + (sm.x_has_d ? 0.0 : d0) + sm.c1 * d0 + sm.c2 * s0,
-                                     xs_[a].y + (sm.x_has_d ? 0.0 : d1) + sm.c1 * d1 + sm.c2 * s1);
+                            const double xn0 = xs_[a].x + (sm.x_has_d ? 0.0 : d0) + sm.c1 * d0 + sm.c2 * s0;
+                            const double xn1 = xs_[a].y + (sm.x_has_d ? 0.0 : d1) + sm.c1 * d1 + sm.c2 * s1;
+                            if (sm.x64) ksfd_st2(sm.x64 + (long long)a * G.plane + o, xn0, xn1);
+                            else ksfd_st2(sm.x + (long long)a * G.plane + o, xn0, xn1);
                         }
                     }
                 }

@@ -284,20 +284,20 @@ def test_stage_guesses_in_the_multigrid_regime_save_iterations_same_answer():
     u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(2)])
     h = 20.0
     un, _, _, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='lu')
-    k = klib.KSFDHip(cfg)
     res = {}
     for name, tune in (('on', 1), ('off', 1 | 16384)):
-        k.set_tuning(use_fused=tune)
         for tol in (1e-6, 1e-11):
+            k = klib.KSFDHip(cfg)            # a handle each: the hierarchy's set-up remembers the previous one (warm power iteration)
+            k.set_tuning(use_fused=tune)
             k.set_state(u)
             t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=tol, pc_type=1))
             assert st.pc_used & 2
             res[name, tol] = (st.linear_its, k.get_state())
+            k.close()
     assert res['on', 1e-6][0] < res['off', 1e-6][0], (res['on', 1e-6][0], res['off', 1e-6][0])
     for name in ('on', 'off'):
         assert rel_l2(res[name, 1e-11][1], un) < 1e-9, name
         assert rel_l2(res[name, 1e-6][1], un) < 5e-6, name    # a residual tolerance: the state follows it to a small factor
-    k.close()
 
 
 @pytest.mark.parametrize('shape,nlig', [((64, 64), 1), ((40, 24), 2), ((32, 32, 32), 1)])
@@ -321,6 +321,38 @@ def test_checkpoint_restore_replays_the_same_steps(shape, nlig):
     def run():
         tt, hh, out = tc, hc, []
         for _ in range(5):
+            tt, hh, st, rc = k.step(tt, hh, opts)
+            out.append((tt, hh, st.linear_its, st.rejections, st.pc_used, k.get_state().copy()))
+        return out
+    first = run()
+    k.restore()
+    second = run()
+    for a, b in zip(first, second):
+        assert a[:5] == b[:5]
+        assert np.array_equal(a[5], b[5])
+    k.close()
+
+
+def test_checkpoint_restore_replays_the_same_steps_in_the_multigrid_regime():
+    """same, with the V cycle as preconditioner (pc_type = 1, h ~ 20): what a multigrid set-up keeps for the next one (the power-iteration
+    vector of every level) is dropped at the save and at the restore, so both replays set the hierarchy up from the same cold start"""
+    cfg = ProblemConfig.standard(2, (64, 64), L=(0.16, 0.16), nlig=2)
+    rng = np.random.default_rng(37)
+    rho = 9000 + 90 * rng.standard_normal(cfg.N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(2)])
+    k = klib.KSFDHip(cfg)
+    k.set_state(u)
+    opts = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, pc_type=1)
+    t, h = 0.0, 5.0
+    for _ in range(3):
+        t, h, st, rc = k.step(t, h, opts)
+        assert st.pc_used & 2
+    k.checkpoint()
+    tc, hc = t, h
+
+    def run():
+        tt, hh, out = tc, hc, []
+        for _ in range(4):
             tt, hh, st, rc = k.step(tt, hh, opts)
             out.append((tt, hh, st.linear_its, st.rejections, st.pc_used, k.get_state().copy()))
         return out
@@ -364,7 +396,7 @@ def test_fused_multigrid_smoother_gives_the_same_iterates(shape):
     u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(cfg.nlig)])
     k = klib.KSFDHip(cfg)
     out = {}
-    for name, tune in (('fused', 1), ('separate', 1 | 4096)):
+    for name, tune in (('fused', 1 | 262144), ('separate', 1 | 4096 | 262144)):      # bit 18: every set-up from the same cold start
         k.set_tuning(use_fused=tune)
         k.set_state(u)
         t, hn, st, rc = k.step(0.0, 10.0, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-10, pc_type=1))
