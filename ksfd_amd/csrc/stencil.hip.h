@@ -472,6 +472,45 @@ __device__ __forceinline__ void ksfd_dxx(double a0, double a1, const KX &x, doub
     d2_0 = KSFD_D2(x.l0, x.l1, a0, a1, x.r0);
     d2_1 = KSFD_D2(x.l1, a0, a1, x.r0, x.r1);
 }
+// The same for a vector STORED in fp32 (the multigrid cycle's level vectors): the window keeps the stored values -- half the registers,
+// one DPP move per neighbour instead of two -- and every difference is formed in fp64.
+struct KXf {
+    float l0, l1, r0, r1;
+};
+__device__ __forceinline__ float ksfd_lane_from_left(float a)
+{
+    int v = __float_as_int(a);
+    v = __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+    return __int_as_float(v);
+}
+__device__ __forceinline__ float ksfd_lane_from_right(float a)
+{
+    int v = __float_as_int(a);
+    v = __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);
+    return __int_as_float(v);
+}
+__device__ __forceinline__ KXf ksfd_xnb(float a0, float a1)
+{
+    KXf x;
+    x.l0 = ksfd_lane_from_left(a0);
+    x.l1 = ksfd_lane_from_left(a1);
+    x.r0 = ksfd_lane_from_right(a0);
+    x.r1 = ksfd_lane_from_right(a1);
+    return x;
+}
+__device__ __forceinline__ void ksfd_dx(float a0, float a1, const KXf &x, double &d1_0, double &d1_1)
+{
+    d1_0 = KSFD_D1((double)x.l0, (double)x.l1, (double)a1, (double)x.r0);
+    d1_1 = KSFD_D1((double)x.l1, (double)a0, (double)x.r0, (double)x.r1);
+}
+__device__ __forceinline__ void ksfd_dxx(float a0, float a1, const KXf &x, double &d2_0, double &d2_1)
+{
+    d2_0 = KSFD_D2((double)x.l0, (double)x.l1, (double)a0, (double)a1, (double)x.r0);
+    d2_1 = KSFD_D2((double)x.l1, (double)a0, (double)a1, (double)x.r0, (double)x.r1);
+}
+// a pair in its storage type
+__device__ __forceinline__ double2 ksfd_ldw(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+__device__ __forceinline__ float2 ksfd_ldw(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
 struct KWaveJob {
     long long wid;      // logical wave id (strip + nstrips * segment slot of this launch)
@@ -912,8 +951,11 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
     // 4: out = alpha*v + beta*(shift*v - J v)      (first Horner step: no extra plane is read)
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;
-    double rw[5][2], gw[5][2], vw[5][2], ew[5][2], zw[NL][5][2];   // rho, G, v_rho, dG, v_U
-    double nr[PF][2], ng[PF][2], nq[PF][2], nv[PF][2], nc[PF][NL][2], nz[PF][NL][2];
+    typedef typename std::conditional<std::is_same<TV, float>::value, float, double>::type WV;     // window of v in its storage type
+    double rw[5][2], gw[5][2], ew[5][2];   // rho, G, dG
+    WV vw[5][2], zw[NL][5][2];             // v_rho, v_U
+    double nr[PF][2], ng[PF][2], nq[PF][2], nc[PF][NL][2];
+    WV nv[PF][2], nz[PF][NL][2];
     double nacc = 0.0;
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, (PF > 1 ? 1 : 0)> B1;
@@ -921,12 +963,13 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
     auto load_row = [&](auto Bc, long long r) {
         constexpr int B = decltype(Bc)::value;
         const long long o = ksfd_rowoff(G, r) + J.c0;
-        double2 a = ksfd_ld2(C + o), b = ksfd_ld2(C + G.plane + o), c = ksfd_ld2(C + 2 * G.plane + o), w = ksfd_ld2(v + o);
+        double2 a = ksfd_ld2(C + o), b = ksfd_ld2(C + G.plane + o), c = ksfd_ld2(C + 2 * G.plane + o);
+        const auto w = ksfd_ldw(v + o);
         nr[B][0] = a.x; nr[B][1] = a.y; ng[B][0] = b.x; ng[B][1] = b.y; nq[B][0] = c.x; nq[B][1] = c.y; nv[B][0] = w.x; nv[B][1] = w.y;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             double2 q = ksfd_ld2(C + (long long)(3 + l) * G.plane + o);
-            double2 z = ksfd_ld2(v + (long long)(l + 1) * G.plane + o);
+            const auto z = ksfd_ldw(v + (long long)(l + 1) * G.plane + o);
             nc[B][l][0] = q.x; nc[B][l][1] = q.y; nz[B][l][0] = z.x; nz[B][l][1] = z.y;
         }
     };
@@ -944,9 +987,9 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            double d = nq[B][e] * nv[B][e];
+            double d = nq[B][e] * (double)nv[B][e];
 #pragma unroll
-            for (int l = 0; l < NL; l++) { d += nc[B][l][e] * nz[B][l][e]; zw[l][4][e] = nz[B][l][e]; }
+            for (int l = 0; l < NL; l++) { d += nc[B][l][e] * (double)nz[B][l][e]; zw[l][4][e] = nz[B][l][e]; }
             rw[4][e] = nr[B][e]; gw[4][e] = ng[B][e]; vw[4][e] = nv[B][e]; ew[4][e] = d;
         }
     };
@@ -959,30 +1002,31 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
         push_row(Bc);
         if (r + PF < J.r1) load_row(Bc, J.row(r + 2 + PF));
         // the added vector of modes 2/3 is needed only at the store: issue its loads now, behind the next row's
-        double2 yv[NL + 1];
+        decltype(ksfd_ldw(yadd)) yv[NL + 1];                 // kept in the storage type until they are used (registers)
         if ((mode == 2 || mode == 3 || (SMOOTH && mode == 5)) && J.store) {
             const long long oy = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
 #pragma unroll
-            for (int c = 0; c <= NL; c++) yv[c] = ksfd_ld2(yadd + (long long)c * G.plane + oy);
+            for (int c = 0; c <= NL; c++) yv[c] = ksfd_ldw(yadd + (long long)c * G.plane + oy);
         }
-        double2 dv_[SMOOTH ? (NL + 1) * (NL + 1) : 1], xs_[SMOOTH ? NL + 1 : 1], rs_[SMOOTH ? NL + 1 : 1];
+        float2 dv_[SMOOTH ? (NL + 1) * (NL + 1) : 1];
+        decltype(ksfd_ldw(sm.rr)) xs_[SMOOTH ? NL + 1 : 1], rs_[SMOOTH ? NL + 1 : 1];
         if constexpr (SMOOTH) {
             if (mode >= 5 && J.store) {
                 const long long oy = (long long)G.ng * G.inner + J.row(r) * G.nx + J.c0;
 #pragma unroll
-                for (int q = 0; q < (NL + 1) * (NL + 1); q++) dv_[q] = ksfd_ld2(sm.dinv + (long long)q * G.plane + oy);
+                for (int q = 0; q < (NL + 1) * (NL + 1); q++) dv_[q] = ksfd_ldw(sm.dinv + (long long)q * G.plane + oy);
                 if (mode == 6) {
 #pragma unroll
                     for (int c = 0; c <= NL; c++) {
-                        xs_[c] = ksfd_ld2(sm.x + (long long)c * G.plane + oy);
-                        rs_[c] = ksfd_ld2(sm.rr + (long long)c * G.plane + oy);
+                        xs_[c] = ksfd_ldw((const TS *)sm.x + (long long)c * G.plane + oy);
+                        rs_[c] = ksfd_ldw(sm.rr + (long long)c * G.plane + oy);
                     }
                 }
             }
         }
         const KX xr = ksfd_xnb(rw[2][0], rw[2][1]);
         const KX xg = ksfd_xnb(gw[2][0], gw[2][1]);
-        const KX xv = ksfd_xnb(vw[2][0], vw[2][1]);
+        const auto xv = ksfd_xnb(vw[2][0], vw[2][1]);
         const KX xe = ksfd_xnb(ew[2][0], ew[2][1]);
         double d1r[2], d1g[2], d1v[2], d1e[2], d2g[2], d2e[2];
         ksfd_dx(rw[2][0], rw[2][1], xr, d1r[0], d1r[1]);
@@ -997,25 +1041,25 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
             const double ih0 = P.inv_h[0], ih1 = P.inv_h[1];
             const double yr = KSFD_D1(rw[0][e], rw[1][e], rw[3][e], rw[4][e]) * ih1;
             const double yg = KSFD_D1(gw[0][e], gw[1][e], gw[3][e], gw[4][e]) * ih1;
-            const double yv = KSFD_D1(vw[0][e], vw[1][e], vw[3][e], vw[4][e]) * ih1;
+            const double yv = KSFD_D1((double)vw[0][e], (double)vw[1][e], (double)vw[3][e], (double)vw[4][e]) * ih1;
             const double ye = KSFD_D1(ew[0][e], ew[1][e], ew[3][e], ew[4][e]) * ih1;
             const double lapG = d2g[e] * P.inv_h2[0] + KSFD_D2(gw[0][e], gw[1][e], gw[2][e], gw[3][e], gw[4][e]) * P.inv_h2[1];
             const double lapE = d2e[e] * P.inv_h2[0] + KSFD_D2(ew[0][e], ew[1][e], ew[2][e], ew[3][e], ew[4][e]) * P.inv_h2[1];
             const double jr = (d1v[e] * ih0) * (d1g[e] * ih0) + (d1r[e] * ih0) * (d1e[e] * ih0) + yv * yg + yr * ye +
-                              vw[2][e] * lapG + rw[2][e] * lapE;
-            res[0][e] = mode ? shift * vw[2][e] - jr : jr;
+                              (double)vw[2][e] * lapG + rw[2][e] * lapE;
+            res[0][e] = mode ? shift * (double)vw[2][e] - jr : jr;
         }
 #pragma unroll
         for (int l = 0; l < NL; l++) {
-            const KX xz = ksfd_xnb(zw[l][2][0], zw[l][2][1]);
+            const auto xz = ksfd_xnb(zw[l][2][0], zw[l][2][1]);
             double d2z[2];
             ksfd_dxx(zw[l][2][0], zw[l][2][1], xz, d2z[0], d2z[1]);
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const double lap = d2z[e] * P.inv_h2[0] +
-                                   KSFD_D2(zw[l][0][e], zw[l][1][e], zw[l][2][e], zw[l][3][e], zw[l][4][e]) * P.inv_h2[1];
-                const double ju = -P.lig_gamma[l] * zw[l][2][e] + P.lig_s[l] * vw[2][e] + P.lig_D[l] * lap;
-                res[l + 1][e] = mode ? shift * zw[l][2][e] - ju : ju;
+                                   KSFD_D2((double)zw[l][0][e], (double)zw[l][1][e], (double)zw[l][2][e], (double)zw[l][3][e], (double)zw[l][4][e]) * P.inv_h2[1];
+                const double ju = -P.lig_gamma[l] * (double)zw[l][2][e] + P.lig_s[l] * (double)vw[2][e] + P.lig_D[l] * lap;
+                res[l + 1][e] = mode ? shift * (double)zw[l][2][e] - ju : ju;
             }
         }
         if (SMOOTH && mode >= 5) {
@@ -1025,21 +1069,21 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                     double q0[NL + 1], q1[NL + 1];                    // mode 5: r = yadd - A v ; mode 6: rr - A d
 #pragma unroll
                     for (int c = 0; c <= NL; c++) {
-                        q0[c] = (mode == 5 ? yv[c].x : rs_[c].x) - res[c][0];
-                        q1[c] = (mode == 5 ? yv[c].y : rs_[c].y) - res[c][1];
+                        q0[c] = (mode == 5 ? (double)yv[c].x : (double)rs_[c].x) - res[c][0];
+                        q1[c] = (mode == 5 ? (double)yv[c].y : (double)rs_[c].y) - res[c][1];
                     }
 #pragma unroll
                     for (int a = 0; a <= NL; a++) {
                         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                        for (int c = 0; c <= NL; c++) { s0 += dv_[a * (NL + 1) + c].x * q0[c]; s1 += dv_[a * (NL + 1) + c].y * q1[c]; }
+                        for (int c = 0; c <= NL; c++) { s0 += (double)dv_[a * (NL + 1) + c].x * q0[c]; s1 += (double)dv_[a * (NL + 1) + c].y * q1[c]; }
                         if (mode == 5) {
                             ksfd_st2(out + (long long)a * G.plane + o, q0[a], q1[a]);
                             ksfd_st2(sm.out2 + (long long)a * G.plane + o, sm.scale * s0, sm.scale * s1);
                         } else {
-                            const double d0 = a == 0 ? vw[2][0] : zw[a > 0 ? a - 1 : 0][2][0], d1 = a == 0 ? vw[2][1] : zw[a > 0 ? a - 1 : 0][2][1];
-                            const double xn0 = xs_[a].x + (sm.x_has_d ? 0.0 : d0) + sm.c1 * d0 + sm.c2 * s0;
-                            const double xn1 = xs_[a].y + (sm.x_has_d ? 0.0 : d1) + sm.c1 * d1 + sm.c2 * s1;
+                            const double d0 = a == 0 ? (double)vw[2][0] : (double)zw[a > 0 ? a - 1 : 0][2][0], d1 = a == 0 ? (double)vw[2][1] : (double)zw[a > 0 ? a - 1 : 0][2][1];
+                            const double xn0 = (double)xs_[a].x + (sm.x_has_d ? 0.0 : d0) + sm.c1 * d0 + sm.c2 * s0;
+                            const double xn1 = (double)xs_[a].y + (sm.x_has_d ? 0.0 : d1) + sm.c1 * d1 + sm.c2 * s1;
                             if (sm.x64) ksfd_st2(sm.x64 + (long long)a * G.plane + o, xn0, xn1);
                             else ksfd_st2(sm.x + (long long)a * G.plane + o, xn0, xn1);
                         }
@@ -1055,7 +1099,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                     const double c0 = c == 0 ? vw[2][0] : zw[c > 0 ? c - 1 : 0][2][0], c1 = c == 0 ? vw[2][1] : zw[c > 0 ? c - 1 : 0][2][1];
                     a = alpha * c0 + beta * a; b = alpha * c1 + beta * b;
                 } else if (mode >= 2) {
-                    const double2 yy = yv[c];
+                    const double2 yy = make_double2((double)yv[c].x, (double)yv[c].y);
                     if (mode == 2) { a = yy.x - a; b = yy.y - b; } else { a = alpha * yy.x + beta * a; b = alpha * yy.y + beta * b; }
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
