@@ -288,8 +288,8 @@ static int mg_smooth(ksfd_handle *h, MGLevel &L, double shift, const double *b, 
         S.dinv = L.dinv; S.x = x; S.c1 = rhon * rho0; S.c2 = 2.0 * rhon / delta;
         if (zero_init) {
             {
-                Scope sc(h, KC_MG, 8.0 * (3 * F + 0.5 * F * F) * L.G.nloc);
-                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), b + off, 1.0 / theta, L.d + off, x + off));
+                Scope sc(h, KC_MG, 8.0 * (2 * F + 0.5 * F * F) * L.G.nloc);
+                NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), b + off, 1.0 / theta, L.d + off));
             }
             S.rr = b; S.x_has_d = 1;
             return mg_op(h, L, L.d, 6, shift, nullptr, nullptr, &S);
@@ -495,13 +495,13 @@ static int mg_vcycle32(ksfd_handle *h, size_t l, double shift, const double *b64
     const long long off = L.kv.off;
     KSmoothT<float> S = KSmoothT<float>{};
     S.dinv = L.dinv; S.x = L.x32; S.c1 = rhon * rho0; S.c2 = 2.0 * rhon / delta;
-    // pre-smoothing from a zero guess: d0 = Dinv b / theta, x = d0 (+ the fp32 copy of b on level 0); then x += d1 in the epilogue of A d0
+    // pre-smoothing from a zero guess: d0 = Dinv b / theta (+ the fp32 copy of b on level 0); then x = d0 + d1 in the epilogue of A d0
     {
-        Scope sc(h, KC_MG, ((b64 ? 8.0 + 4.0 : 4.0) * F + 8.0 * F + 4.0 * F * F) * (double)L.G.nloc);
+        Scope sc(h, KC_MG, ((b64 ? 8.0 + 4.0 : 4.0) * F + 4.0 * F + 4.0 * F * F) * (double)L.G.nloc);
         if (b64) {
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL, double, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), b64 + off, 1.0 / theta, L.d32 + off, L.x32 + off, L.b32 + off));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL, double, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), b64 + off, 1.0 / theta, L.d32 + off, (float *)nullptr, L.b32 + off));
         } else {
-            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL, float, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), (const float *)(L.b32 + off), 1.0 / theta, L.d32 + off, L.x32 + off));
+            NL_DISPATCH(h->P.nlig, hipLaunchKernelGGL((k_dinv_apply<NL, float, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, L.G.nloc, L.G.plane, (const float *)(L.dinv + off), (const float *)(L.b32 + off), 1.0 / theta, L.d32 + off));
         }
     }
     S.rr = L.b32; S.x_has_d = 1;

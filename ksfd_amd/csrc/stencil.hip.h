@@ -28,7 +28,8 @@ struct KComb {
 
 // Smoother algebra of the multigrid preconditioner folded into the Jacobian-action epilogue (modes 5 and 6):
 //   5:  r = yadd - A v  -> out ;  d = scale * Dinv r -> out2                (residual + first Chebyshev direction)
-//   6:  x += (x_has_d ? 0 : d) + c1*d + c2 * Dinv (rr - A d),  v = d        (k_cheb_last without the A d round trip)
+//   6:  x = (x_has_d ? d : x + d) + c1*d + c2 * Dinv (rr - A d),  v = d     (k_cheb_last without the A d round trip; x_has_d: first sweep
+//       from a zero guess, x would be d itself and is neither written beforehand nor read)
 // Dinv: F*F planes of the inverse point-block diagonal (row-major), all vectors in the level's ghosted layout.
 template <typename TS = double>
 struct KSmoothT {
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp_generic(KGeom G, KPhys P, co
                 for (int c = 0; c <= NL; c++) s += sm.dinv[(long long)(a * (NL + 1) + c) * G.plane + o] * q[c];
                 const long long oa = (long long)a * G.plane + o;
                 if (mode == 5) { out[oa] = q[a]; sm.out2[oa] = sm.scale * s; }
-                else sm.x[oa] += (sm.x_has_d ? 0.0 : dc[a]) + sm.c1 * dc[a] + sm.c2 * s;
+                else sm.x[oa] = (sm.x_has_d ? dc[a] : sm.x[oa] + dc[a]) + sm.c1 * dc[a] + sm.c2 * s;       // x_has_d: x == d == v, not read
             }
             continue;
         }
@@ -1018,7 +1019,7 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                 if (mode == 6) {
 #pragma unroll
                     for (int c = 0; c <= NL; c++) {
-                        xs_[c] = ksfd_ldw((const TS *)sm.x + (long long)c * G.plane + oy);
+                        if (!sm.x_has_d) xs_[c] = ksfd_ldw((const TS *)sm.x + (long long)c * G.plane + oy);     // x_has_d: x == d, which is v itself
                         rs_[c] = ksfd_ldw(sm.rr + (long long)c * G.plane + oy);
                     }
                 }
@@ -1082,8 +1083,8 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_jvp2d_frozen(KGeom G, KPhys P, K
                             ksfd_st2(sm.out2 + (long long)a * G.plane + o, sm.scale * s0, sm.scale * s1);
                         } else {
                             const double d0 = a == 0 ? (double)vw[2][0] : (double)zw[a > 0 ? a - 1 : 0][2][0], d1 = a == 0 ? (double)vw[2][1] : (double)zw[a > 0 ? a - 1 : 0][2][1];
-                            const double xn0 = (double)xs_[a].x + (sm.x_has_d ? 0.0 : d0) + sm.c1 * d0 + sm.c2 * s0;
-                            const double xn1 = (double)xs_[a].y + (sm.x_has_d ? 0.0 : d1) + sm.c1 * d1 + sm.c2 * s1;
+                            const double xn0 = (sm.x_has_d ? d0 : (double)xs_[a].x + d0) + sm.c1 * d0 + sm.c2 * s0;
+                            const double xn1 = (sm.x_has_d ? d1 : (double)xs_[a].y + d1) + sm.c1 * d1 + sm.c2 * s1;
                             if (sm.x64) ksfd_st2(sm.x64 + (long long)a * G.plane + o, xn0, xn1);
                             else ksfd_st2(sm.x + (long long)a * G.plane + o, xn0, xn1);
                         }
