@@ -803,6 +803,10 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
             }
             st.linear_its += ls.its;
             st.ksp_resid = ls.rel;
+            {
+                static const bool stage_trace = getenv("KSFD_STAGE_TRACE") != nullptr;     // iterations per stage system (diagnostics)
+                if (stage_trace) fprintf(stderr, "[stage %d] its %d rel %.2e guess %d\n", i, ls.its, ls.rel, sg.n);
+            }
             if (rc == KSFD_ELINEAR && !use_pc && h->mg_ok && h->use_frozen && opts->pc_type) {
                 // unpreconditioned GMRES ran out of iterations: the multigrid-preconditioned solve of the same system
                 // is the remedy (the stiffness estimate above only knows the diffusion part of J)
