@@ -707,9 +707,9 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                     if (h->At[i][j] != 0.0) { cmb.yin[cmb.nin] = h->Y + (int64_t)j * vs; cmb.ain[cmb.nin++] = h->At[i][j]; }
                     if (h->Ginv[i][j] != 0.0) { cmb.yout[cmb.nout] = h->Y + (int64_t)j * vs; cmb.aout[cmb.nout++] = -h->Ginv[i][j] / hh; }
                 }
-                if (i > 0 && (rc = halo(h, h->Y + (int64_t)(i - 1) * vs))) break;     // ghosts of the newest stage vector (earlier ones done)
                 const bool rhs_norm = use_spec && fused_ok(h) && !(guess_on && i > 0);      // ||b||^2 from the store epilogue (2-D strip kernel)
-                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, rhs_norm))) break;
+                // ghosts of the newest stage vector (earlier ones done): exchanged behind the interior rows of the RHS (op_rhs)
+                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, rhs_norm, i > 0 ? h->Y + (int64_t)(i - 1) * vs : nullptr))) break;
                 if (rhs_norm) bnorm2 = h->hres[0];
             } else {
             if (i > 0) {

@@ -192,12 +192,16 @@ static KSrc src_of(const ksfd_handle *h, int stage)
 static inline long long part_capacity() { return (long long)(2 * KSFD_MAXDOT + 4) * 4096; }
 
 // want_norm (fused 2-D path only): ||out||^2 lands in h->hres[0] without a pass of its own (per-wave partials in the store epilogue)
-static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr, bool want_norm = false)
+// halo_vec (slab ranks): a vector among the inputs whose ghost rows have NOT been exchanged yet (the newest stage vector).  On the
+// 2-D strip path they travel on the communication stream while the interior segments are computed -- the scheme of
+// op_jvp_frozen_halo: only the first and the last segment read ghost rows -- elsewhere they are exchanged first.
+static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr, bool want_norm = false, double *halo_vec = nullptr)
 {
     const KGeom &G = h->G;
     KSrc S = src_of(h, stage);
     // time-dependent parameters: the reference evaluates ps.values(t) at the STAGE time of every RHS call
     const KPhys &PP = (stage >= 0 && stage < 4 && h->Pst_valid[stage]) ? h->Pst[stage] : h->P;
+    if (!h->ring) halo_vec = nullptr;
     if (fused_ok(h)) {
         KStrips K = make_strips(h);
         KComb C = cmb ? *cmb : KComb{};
@@ -206,16 +210,42 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         // the vectors added at the store are the ones the stage argument is formed from: one read serves both (k_rhs2d_fused<NL, true>)
         bool carry = h->rhs_carry && C.nout > 0 && C.nout == C.nin;
         for (int j = 0; j < C.nout && carry; j++) carry = C.yin[j] == C.yout[j];
-        {
-            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + (carry ? 0 : C.nout)), vbytes(h, 2 + C.nin + C.nout));
-            if (carry) { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL, true>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr)); }
-            else { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, u, S, out, C, fused_norm ? h->part : (double *)nullptr)); }
+        auto launch = [&](const KStrips &Kx, double frac, double *np) {
+            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + (carry ? 0 : C.nout)) * frac, vbytes(h, 2 + C.nin + C.nout) * frac);
+            if (carry) { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL, true>), dim3(Kx.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, Kx, u, S, out, C, np)); }
+            else { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(Kx.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, Kx, u, S, out, C, np)); }
+        };
+        double *np = fused_norm ? h->part : (double *)nullptr;
+        const bool ovl = halo_vec && h->overlap && K.nseg >= 3;
+        if (halo_vec && !ovl) { int rc = halo(h, halo_vec); if (rc) return rc; }
+        if (!ovl) launch(K, 1.0, np);
+        else {
+            HIPCHK(h, hipEventRecord(h->ev_ready, h->st));
+            KStrips Ki = K;
+            Ki.seg0 = 1; Ki.seg_stride = 1; Ki.nseg = K.nseg - 2;
+            long long nb = ((long long)Ki.nstrips * Ki.nseg + 3) / 4;
+            Ki.nblocks = (int)((nb + 7) / 8 * 8);
+            launch(Ki, (double)Ki.nseg / K.nseg, np);
+            HIPCHK(h, hipStreamWaitEvent(h->st_comm, h->ev_ready, 0));
+            {
+                Scope sc(h, KC_HALO, 4.0 * 2.0 * 8.0 * G.F * (double)G.inner * 2.0);
+                if (h->tr->exchange(halo_vec, G.F, G.plane, G.inner, G.sloc, G.ng, h->st_comm)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+            }
+            HIPCHK(h, hipEventRecord(h->ev_halo, h->st_comm));
+            HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_halo, 0));
+            KStrips Kb = K;
+            Kb.seg0 = 0; Kb.seg_stride = K.nseg - 1; Kb.nseg = 2;
+            nb = ((long long)Kb.nstrips * Kb.nseg + 3) / 4;
+            Kb.nblocks = (int)((nb + 7) / 8 * 8);
+            launch(Kb, 2.0 / K.nseg, np ? np + (long long)K.nstrips * (K.nseg - 2) : nullptr);
         }
         HIPCHK(h, hipGetLastError());
         if (fused_norm) return reduce_rows(h, 1, (int)nwaves, 0);
         if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm needs the strip kernels");
         return KSFD_OK;
-    } else if (strip3d_ok(h) && h->rhs3d_strip) {
+    }
+    if (halo_vec) { int rc = halo(h, halo_vec); if (rc) return rc; }
+    if (strip3d_ok(h) && h->rhs3d_strip) {
         // 3-D: G plane (+ the stage argument, when the stage algebra rides along), then the z-marching 13-point star
         if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm is a 2-D feature");
         KComb C = cmb ? *cmb : KComb{};
