@@ -67,6 +67,7 @@ def parse_args(argv=None):
                     help='torch.distributed backend for launch/timing; gloo + --transport host lets several ranks share one GPU (rehearsal)')
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true', help='take roofline.traffic from the committed PMC summary instead of measuring it in two rocprofv3 child runs')
     ap.add_argument('--cpu-sample-n', type=int, default=1024)
     ap.add_argument('--cpu-lu-n', type=int, default=256, help='grid of the sparse-LU CPU baseline (0 skips it); SuperLU needs ~15 s at 256^2, > 80 s at 512^2')
     ap.add_argument('--agg-tile', type=int, default=256, help='grid of the run that produces the aggregated state (0 skips the leg)')
@@ -306,6 +307,11 @@ def main():
                 for k, v in table.items() if v['launches']}
         default_workload = world == 1 and args.n == 4096 and args.dim == 2 and args.nlig == 1
         traffic, traffic_src = pmc_traffic(dom) if default_workload else (None, None)
+        live_err = None
+        if default_workload and not args.no_live_pmc:
+            lt, live_err = live_pmc(args, dom)
+            if lt:
+                traffic, traffic_src, live_err = lt, 'live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of this command (ramp + 7 steps of the window), 2*FETCH_SIZE + WRITE_SIZE', None
         rp_us, rp_src = rocprof_avg_us(dom) if default_workload else (None, None)
         out = {
             'metric': 'grid-point-updates/sec (implicit step)', 'value': value, 'unit': 'grid-point-updates/s',
@@ -331,7 +337,7 @@ def main():
                          'frac_algorithmic': gbs(alg_bytes) / HBM_PEAK_GBS,
                          # bytes the implementation has to move per launch (frozen-coefficient planes, fused operands)
                          'frac_implementation': gbs(impl_bytes) / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'traffic_live_error': live_err,
                          'alg_bytes_per_launch': alg_bytes, 'impl_bytes_per_launch': impl_bytes, 'ms_per_launch': per_launch_ms,
                          'launches': int(d['launches']), 'rocprof_avg_us': rp_us, 'rocprof_source': rp_src,
                          # whole step over the wall clock of the timed region: bytes the implementation moves, and SURVEY 8d's
@@ -408,6 +414,54 @@ def aggregated_leg(args, klib, np):
             'steps_by_solver': pcs, 'rejections': rej, 'h_mean': float(np.mean(hs)), 't': t,
             'rho_min': float(rho.min()), 'rho_max': float(rho.max()),
             'state': '%dx%d run (options81 spacing) from dt0=1e-8, %d steps in %.1f s to t=%.4g, tiled %dx%d' % (m, m, nst, setup_s, t, reps, reps)}
+
+
+PMC_CLASS_PATTERNS = {'spectral': ('k_spec',), 'jvp': ('k_jvp',), 'rhs': ('k_rhs',), 'multidot': ('k_multidot',), 'mg': ('k_mg_', 'k_cheb', 'k_restrict', 'k_prolong')}
+
+
+def live_pmc(args, kernel_class):
+    """HBM bytes per launch of a kernel class measured in THIS invocation: two child runs of this very command (same grid and window, 5 timed
+    steps, no side legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only beside the kernel trace,
+    as /opt/skills/guides/MI355X_MICROARCH.md prescribes; gfx950: FETCH_SIZE counts the 128-B requests of 16-B/lane reads at 64 B, hence
+    2*FETCH_SIZE + WRITE_SIZE (KB).  Returns (bytes per launch or None, error text or None); never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    pats = PMC_CLASS_PATTERNS.get(kernel_class)
+    if not pats:
+        return None, 'no kernel-name pattern for class %s' % kernel_class
+    if any('rocprof' in os.environ.get(k, '') for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES')):
+        return None, 'already running under a profiler'
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if not exe:
+        return None, 'rocprofv3 not found'
+    avg = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='ksfd_pmc_', dir='/tmp')
+        try:
+            cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__),
+                   '--gpus', '1', '--steps', '5', '--warmup', '2', '--grid', str(args.n), '--nlig', str(args.nlig), '--dim', str(args.dim),
+                   '--no-cpu-baseline', '--no-live-pmc', '--agg-tile', '0', '--fixed-h', '0']
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                return None, 'rocprofv3 --pmc %s exited with %d: %s' % (counter, r.returncode, r.stderr.decode(errors='replace')[-200:])
+            n, tot = 0, 0.0
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get('Counter_Name') == counter and any(p_ in row['Kernel_Name'] for p_ in pats):
+                            n += 1
+                            tot += float(row['Counter_Value'])
+            if n == 0:
+                return None, 'no %s rows for class %s' % (counter, kernel_class)
+            avg[counter] = tot / n
+        except Exception as e:                                   # a profiler problem must never cost the bench line
+            return None, '%s: %s' % (type(e).__name__, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * avg['FETCH_SIZE'] + avg['WRITE_SIZE']) * 1024.0, None
 
 
 def pmc_traffic(kernel_class):

@@ -42,6 +42,8 @@ kb = klib.KSFDHip(big)
 kb.set_state(np.tile(u, (1, reps, reps)).reshape(-1))
 if os.environ.get('MG_NU'):
     kb.set_mg_params(nu=int(os.environ['MG_NU']))
+if os.environ.get('MG_RATIO'):
+    kb.set_mg_params(ratio=float(os.environ['MG_RATIO']))
 if os.environ.get('KSFD_TUNE_BITS'):
     kb.set_tuning(use_fused=1 | int(os.environ['KSFD_TUNE_BITS']))
 if os.environ.get('MG_EAGER'):
