@@ -406,6 +406,38 @@ def test_fused_multigrid_smoother_gives_the_same_iterates(shape):
     k.close()
 
 
+@pytest.mark.parametrize('shape,nlig', [((32, 32), 2), ((64, 48), 1), ((96, 64), 3), ((64, 64), 4), ((36, 36), 2), ((256, 32), 1)])
+def test_multigrid_cycle_with_fp32_level_vectors(shape, nlig):
+    """ksp_rtol >= 1e-8: the V cycle keeps its level vectors in fp32 (mg_vcycle32; arithmetic fp64, GMRES and its true-residual test fp64).
+    Same step as with the fp64 cycle (KSFD_TUNE bit 19) to the solve tolerance, iteration counts within one per stage, and (32^2, where the
+    sparse LU takes seconds) the oracle's LU step to 5e-6 -- one to four ligands, a grid whose second level is already the coarsest one (36^2: only level 0 runs in fp32), a slab-shaped one."""
+    L = tuple(0.0025 * n for n in shape)
+    if nlig <= 2:
+        cfg = ProblemConfig.standard(2, shape, L=L, nlig=nlig)
+    else:                                   # attractant + repellent of options84, then two more of the same kinds in their own groups
+        cfg = ProblemConfig(dim=2, n=shape, L=L, lig_group=[0, 1, 0, 1][:nlig], lig_w=[1.0, 1.0, 0.5, 0.7][:nlig],
+                            lig_s=[0.01, 0.001, 0.003, 0.02][:nlig], lig_gamma=[0.01, 0.001, 0.004, 0.01][:nlig],
+                            lig_D=[1e-6, 1e-5, 3e-6, 2e-6][:nlig], grp_alpha=[1500.0, 1500.0], grp_beta=[5.56e-4, -5.56e-4])
+    rng = np.random.default_rng(41)
+    rho = 9000 + 90 * rng.standard_normal(cfg.N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(nlig)])
+    h = 10.0
+    out = {}
+    for name, tune in (('fp32', 1), ('fp64', 1 | 524288)):
+        k = klib.KSFDHip(cfg)
+        k.set_tuning(use_fused=tune)
+        k.set_state(u)
+        t, hn, st, rc = k.step(0.0, h, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-7, pc_type=1))
+        assert st.pc_used & 2
+        out[name] = (st.linear_its, k.get_state())
+        k.close()
+    assert abs(out['fp32'][0] - out['fp64'][0]) <= 4, (out['fp32'][0], out['fp64'][0])
+    assert rel_l2(out['fp32'][1], out['fp64'][1]) < 2e-7
+    if shape == (32, 32):
+        un, _, _, _ = ko.Oracle(cfg).rosw_step(u, h, 0.01, 1e-6, solver='lu')
+        assert rel_l2(out['fp32'][1], un) < 5e-6
+
+
 @pytest.mark.parametrize('n,h', [(96, 5.0), (384, 50.0), (130, 2.0)])
 def test_multigrid_1d_stiff_step_vs_oracle_lu(n, h):
     """1-D hierarchy (weights 1/4, 1/2, 1/4 / linear interpolation; four of the six option files the reference ships are 1-D)"""
