@@ -25,6 +25,7 @@ struct MGLevel {
     float *dinv = nullptr;     // F*F planes (fp32)
     double *x = nullptr, *b = nullptr, *r = nullptr, *d = nullptr, *Ad = nullptr, *dG = nullptr;
     float *x32 = nullptr, *b32 = nullptr, *r32 = nullptr, *d32 = nullptr;   // level vectors of the fp32 V cycle (f32 levels only)
+    float *coef32 = nullptr;   // fp32 copy of the coefficient planes of a coarse f32 level (level 0 uses the handle's)
     bool f32 = false;          // this level can run the fp32 cycle (2-D strip kernel, not the coarsest level)
     double *pv = nullptr;      // power-iteration vector of Dinv*A, kept from one set-up to the next (warm start)
     double pv_norm = 0.0;      // its norm; 0 = no vector yet

@@ -13,7 +13,7 @@ static void mg_free(ksfd_handle *h)
         if (L.dinv) hipFree(L.dinv);
         double *bufs[] = { l ? L.coef : nullptr, l ? L.x : nullptr, l ? L.b : nullptr, L.r, L.d, L.Ad, L.dG, L.pv };
         for (double *b : bufs) if (b) hipFree(b);
-        float *fb[] = { L.x32, L.b32, L.r32, L.d32 };
+        float *fb[] = { L.x32, L.b32, L.r32, L.d32, L.coef32 };
         for (float *b : fb) if (b) hipFree(b);
     }
     h->mg.clear();
@@ -56,9 +56,9 @@ static int mg_build(ksfd_handle *h)
     }
     h->mg_ok = h->mg.size() >= 2;
     if (h->ring) h->mg_use_graph = false;           // collectives inside the cycle: keep eager launches
-    // fp32 level vectors (mg_vcycle32): one rank, 2-D, levels the strip kernel serves, never the coarsest one (its many Chebyshev sweeps
+    // fp32 level vectors (mg_vcycle32): 2-D, levels the strip kernel serves, never the coarsest one (its many Chebyshev sweeps
     // stay in fp64 with the kernels they have)
-    if (h->mg_ok && dim == 2 && !h->ring && h->use_fused && nl <= 4) {
+    if (h->mg_ok && dim == 2 && h->use_fused && nl <= 4) {
         for (size_t l = 0; l + 1 < h->mg.size(); l++) {
             MGLevel &L = h->mg[l];
             if ((L.G.nx % 2) || L.G.nx < 16) break;
@@ -67,6 +67,7 @@ static int mg_build(ksfd_handle *h)
                 hipMalloc((void **)&L.r32, nb) != hipSuccess || hipMalloc((void **)&L.d32, nb) != hipSuccess) { (void)hipGetLastError(); break; }
             float *zero[] = { L.x32, L.b32, L.r32, L.d32 };
             for (float *z : zero) hipMemsetAsync(z, 0, nb, h->st);
+            if (l > 0 && hipMalloc((void **)&L.coef32, sizeof(float) * (size_t)(3 + nl) * L.G.plane) != hipSuccess) { (void)hipGetLastError(); L.coef32 = nullptr; }
             L.f32 = true;
         }
     }
@@ -112,6 +113,15 @@ static int mg_halo(ksfd_handle *h, MGLevel &L, double *v, int np)
 
 // out = J v | shift v - J v | yadd - (shift v - J v) on level L
 // sm != NULL: modes 5 / 6, smoother algebra in the epilogue (2-D strip kernel and generic kernel only: see mg_can_fuse)
+// ... of an fp32 level vector: it travels through the double-typed transport as half as many doubles (nx is even on these levels)
+static int mg_halo32(ksfd_handle *h, MGLevel &L, float *v, int np)
+{
+    if (!h->ring) return KSFD_OK;
+    Scope sc(h, KC_HALO, 4.0 * 4.0 * np * (double)L.G.inner * 2.0);
+    if (h->tr->exchange(reinterpret_cast<double *>(v), np, L.G.plane / 2, L.G.inner / 2, L.G.sloc, L.G.ng, h->st)) return fail(h, KSFD_ECOMM, "halo exchange failed: %s", h->tr->error().c_str());
+    return KSFD_OK;
+}
+
 static bool mg_can_fuse(const ksfd_handle *h, const MGLevel &L)
 {
     const KGeom &G = L.G;
@@ -208,6 +218,16 @@ static int mg_restrict_coefs(ksfd_handle *h)
             mg_launch_restrict(h, Lf, Lc, np, Lf.coef, Lc.coef);
         }
         if ((rc = mg_halo(h, Lc, Lc.coef, np))) return rc;       // fine ghosts were valid; now the coarse ones are too
+        if (Lc.coef32) {
+            // the fp32 cycle reads an fp32 copy (the same full weighting of the fine fp64 planes, rounded once)
+            int nb = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+            {
+                Scope sc(h, KC_MG, np * (8.0 * Lf.G.nloc + 4.0 * Lc.G.nloc));
+                hipLaunchKernelGGL((k_restrict2d<double, float>), dim3(nb), dim3(KSFD_BLOCK), 0, h->st, np, Lf.G.nx, Lf.G.sloc, Lf.G.wrap_slow,
+                                   (const double *)Lf.coef, Lf.G.plane, Lf.kv.off, Lc.coef32, Lc.G.plane, Lc.kv.off);
+            }
+            if ((rc = mg_halo32(h, Lc, Lc.coef32, np))) return rc;
+        }
     }
     HIPCHK(h, hipGetLastError());
     h->mg_coef_valid = true;
@@ -416,16 +436,17 @@ static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, do
 // The same V(2,2) cycle with fp32 LEVEL VECTORS (x, b, r, d of every f32 level; the arithmetic inside the kernels stays fp64).
 // A V cycle is a preconditioner: GMRES sees the true fp64 residual of the real system whatever the cycle returns, and the cycle is
 // bandwidth-bound -- at 4096^2 x 3 fields an iteration moves ~82 planes of 134 MB through level 0 alone, two thirds of them level
-// vectors.  Used when the step's ksp_rtol >= 1e-8 (ksfd_step; the parity tests at 1e-11 keep the fp64 cycle), one rank, 2-D,
-// V(2,2) with the fused smoother.  The fp64 right-hand side is read once (k_dinv_apply leaves its fp32 copy), the last smoothing
+// vectors.  Used when the step's ksp_rtol >= 1e-8 (ksfd_step; the parity tests at 1e-11 keep the fp64 cycle), 2-D, one rank or slab
+// ranks (a float plane travels through the double-typed transport as half as many doubles), V(2,2) with the fused smoother.  The fp64 right-hand side is read once (k_dinv_apply leaves its fp32 copy), the last smoothing
 // kernel writes the result in fp64 (KSmoothT::x64); levels below the last f32 one run the fp64 code above, the transfer kernels
 // convert at that border.
 // ------------------------------------------------------------------------------------------------
 static int mg_op32(ksfd_handle *h, MGLevel &L, const float *v, int mode, double shift, float *out, const float *yadd, const KSmoothT<float> *sm)
 {
     const KGeom &G = L.G;
+    if (h->ring) { int rch = mg_halo32(h, L, const_cast<float *>(v), G.F); if (rch) return rch; }
     const int cls = (&L == &h->mg[0]) ? KC_JVP : KC_MG;
-    const float *c32 = (&L == &h->mg[0] && h->poly_fp32) ? h->coef32 : nullptr;
+    const float *c32 = (&L == &h->mg[0]) ? (h->poly_fp32 ? h->coef32 : nullptr) : L.coef32;
     // planes moved (in units of 8 B per point): coefficients, v, per mode: 2: yadd + out; 5: yadd, Dinv, r, d; 6: Dinv, rr, x in and out
     const double by = ((c32 ? 4.0 : 8.0) * (3 + h->P.nlig) + 4.0 * G.F + (mode == 2 ? 8.0 * G.F : 12.0 * G.F + 4.0 * G.F * G.F + ((sm && sm->x64) ? 4.0 * G.F : 0.0))) * (double)G.nloc;
     KStrips K;
@@ -465,6 +486,7 @@ static int mg_coarse_correction32(ksfd_handle *h, size_t l, double shift)
     const int F = L.G.F;
     const int nbr = (int)std::min<long long>((Lc.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
     const int nbp = (int)std::min<long long>((L.G.nloc + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
+    if ((rc = mg_halo32(h, L, L.r32, F))) return rc;                    // restriction reads fine rows -1 and sloc
     {
         Scope sc(h, KC_MG, F * (4.0 * L.G.nloc + (Lc.f32 ? 4.0 : 8.0) * Lc.G.nloc));
         if (Lc.f32) hipLaunchKernelGGL((k_restrict2d<float, float>), dim3(nbr), dim3(KSFD_BLOCK), 0, h->st, F, L.G.nx, L.G.sloc, L.G.wrap_slow, (const float *)L.r32, L.G.plane, L.kv.off, Lc.b32, Lc.G.plane, Lc.kv.off);
@@ -473,6 +495,7 @@ static int mg_coarse_correction32(ksfd_handle *h, size_t l, double shift)
     if (Lc.f32) rc = mg_vcycle32(h, l + 1, shift, nullptr, nullptr);
     else rc = mg_vcycle(h, l + 1, shift, Lc.b, Lc.x);
     if (rc) return rc;
+    if ((rc = Lc.f32 ? mg_halo32(h, Lc, Lc.x32, F) : mg_halo(h, Lc, Lc.x, F))) return rc;      // prolongation reads coarse row sloc_c
     {
         Scope sc(h, KC_MG, F * (8.0 * L.G.nloc + (Lc.f32 ? 4.0 : 8.0) * Lc.G.nloc));
         if (Lc.f32) hipLaunchKernelGGL((k_prolong_add2d<float, float>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, F, L.G.nx, L.G.sloc, L.G.wrap_slow, (const float *)Lc.x32, Lc.G.plane, Lc.kv.off, L.x32, L.G.plane, L.kv.off);

@@ -75,6 +75,12 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
         got['mg_its'] = np.float64(st_mg.linear_its)
         got['state'] = gather_slabs(ks.get_state(), cfg)
         got['t'], got['h'] = t, h
+        # ... and one more at a production tolerance: the V cycle then keeps its level vectors in fp32 (2-D; float halo rows travel
+        # through the double-typed transport as half as many doubles)
+        loose = klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, ksp_rtol=1e-7, pc_type=1)
+        t2, _, st_32, rc = ks.step(t, 5.0, loose)
+        got['mg32_its'] = np.float64(st_32.linear_its)
+        got['state32'] = gather_slabs(ks.get_state(), cfg)
         ks.close()
         if rank == 0:
             one = klib.KSFDHip(cfg)
@@ -91,6 +97,9 @@ def _worker(rank, size, port, shape, nlig, transport, outfile):
             t1, hs1, st1mg, rc = one.step(t1, 5.0, stiff)
             ref['mg_its'] = np.float64(st1mg.linear_its)
             ref['state'], ref['t'], ref['h'] = one.get_state(), t1, h1
+            t2, _, st1_32, rc = one.step(t1, 5.0, loose)
+            ref['mg32_its'] = np.float64(st1_32.linear_its)
+            ref['state32'] = one.get_state()
             one.close()
             np.savez(outfile, **{'got_' + k: np.asarray(got[k]) for k in got}, **{'ref_' + k: np.asarray(ref[k]) for k in ref})
     finally:
@@ -107,7 +116,9 @@ def _run(size, shape, nlig, transport, tmp_path):
     for k in ('rhs', 'jvp', 'csr_jv'):
         assert rel_l2(z['got_' + k], z['ref_' + k]) < 1e-11, k
     assert rel_l2(z['got_state'], z['ref_state']) < 1e-9          # includes one h=5 step solved to ksp_rtol=1e-11
+    assert rel_l2(z['got_state32'], z['ref_state32']) < 2e-6        # ... and one solved to 1e-7 through the fp32 V cycle (2-D)
     if len(shape) <= 2 or shape == (16, 16, 32):
+        assert z['got_mg32_its'] <= 2 * z['ref_mg32_its'] + 8, (z['got_mg32_its'], z['ref_mg32_its'])
         # the slab hierarchy may be shallower than the single-rank one, never dramatically worse
         assert z['got_mg_its'] <= 2 * z['ref_mg_its'] + 8, (z['got_mg_its'], z['ref_mg_its'])
     for k in ('vmax', 'worms', 't', 'h'):
