@@ -171,11 +171,12 @@ struct ksfd_handle {
     int snap_next = 0;
 
     // Krylov recycling across the four stage systems of one step (same matrix): see gmres()
-    struct RecSpace { bool valid = false; int vb = 0, zb = 0, k = 0, pc = 0; double H[20]; };   // leading (k+1) x k raw Hessenberg, ld = k+1
+    struct RecSpace { bool valid = false; int vb = 0, zb = 0, k = 0, pc = 0; std::vector<double> H; };   // leading (k+1) x k raw Hessenberg, ld = k+1
     RecSpace rec[4];
     int rec_vtop = 0, rec_ztop = 0;  // first free slot of V / Zb behind the kept vectors
     int rec_mode = 1;                // 0 off, 1 selected earlier stages (default), 2 every earlier stage
     int rec_keep = 3;                // leading vectors kept per stage (<= 4)
+    bool rec_mg = false;             // multigrid-preconditioned solves: the WHOLE first cycle of every stage is kept for the later stages of the step (KSFD_TUNE bit 20 sets; measured: no gain, see gmres)
 
     // multigrid preconditioner
     std::vector<MGLevel> mg;

@@ -118,8 +118,8 @@ static void rec_reset(ksfd_handle *h)
 // Least squares min ||g - H y|| for a small upper-Hessenberg H ((k+1) x k, column-major, ld = k+1); also returns H y.
 static void hess_lsq(const double *H, int k, const double *g, double *y, double *Hy)
 {
-    double R[20], q[5];
     const int ld = k + 1;
+    std::vector<double> R((size_t)ld * k), q((size_t)k + 1);
     for (int i = 0; i < ld * k; i++) R[i] = H[i];
     for (int i = 0; i <= k; i++) q[i] = g[i];
     for (int j = 0; j < k; j++) {
@@ -171,17 +171,23 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     const int m_opt = std::min(o->ksp_restart > 0 ? o->ksp_restart : 30, h->restart_alloc);
     const int maxit = o->ksp_max_it > 0 ? o->ksp_max_it : 2000;
     const int64_t vs = h->vlen;
-    // (not with the multigrid preconditioner: there x0 costs a V cycle per space and, measured on the 600-step 384^2 run,
-    //  buys no iterations -- 20.4 s with, 18.9 s without)
-    bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen && !use_pc;
-    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < 6) { if (stage != 0) rec_on = false; rec_reset(h); }
+    // With the multigrid preconditioner the LEADING vectors of an earlier stage buy nothing (measured on the 600-step 384^2 run:
+    // 20.4 s with, 18.9 s without).  Round 3 tried the other end (rec_full, KSFD_TUNE bit 20, off by default): keep the WHOLE first
+    // cycle of every stage -- the slow modes of shift*I - J that take the iterations late in a run sit in the tail of the Krylov
+    // space -- and project a later stage's right-hand side on A M^-1 V_k = V_k+1 H_k first (one multi-dot, one basis combination,
+    // ONE V cycle for all spaces together).  Measured: it does NOT pay -- aggregated state at 4096^2 x 3 (h = 4.4) 25 instead of 26
+    // iterations per step but 142 instead of 125 ms; indefinite tail of the 384^2 run (h = 400, tools/late_phase.py) 142 instead of
+    // 135 iterations per step.  What a later stage still has to resolve is not in the span of what an earlier one built.
+    const bool rec_full = use_pc && h->rec_mg && stage >= 0 && stage < 4 && h->use_frozen && h->rec_mode > 0;
+    bool rec_on = stage >= 0 && stage < 4 && h->rec_mode > 0 && h->use_frozen && (!use_pc || rec_full);
+    if (!rec_on || stage == 0 || h->restart_alloc - h->rec_vtop < (rec_full ? 16 : 6)) { if (stage != 0) rec_on = false; rec_reset(h); }
     const int vb = rec_on ? h->rec_vtop : 0, zb = rec_on ? h->rec_ztop : 0;
     // Restart length.  The first cycle runs with ksp_restart (30: PETSc's default); a cycle that ends without convergence is followed by
     // one of twice the length, up to what ksfd_create could allocate (restart_alloc, <= 120).  Restarted GMRES loses most on exactly the
     // systems where it needs many iterations -- shift*I - J indefinite late in a run, 30-50 iterations per stage system -- and a longer
     // basis costs little next to the V cycle and Jacobian actions of an iteration there.  Host arrays are sized for the longest cycle.
     const int m = h->restart_alloc - vb;
-    int m_cur = std::min(m_opt, m);
+    int m_cur = (rec_full && rec_on) ? m : std::min(m_opt, m);          // rec_full: no restart inside the space that is going to be kept
     double *V = h->V + (int64_t)vb * vs;
     double *Zq = use_poly ? h->Zb + (int64_t)zb * vs : nullptr;
     int rc;
@@ -190,10 +196,10 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     // reduction and one host round trip less per stage
     static const int sel[4][3] = { { -1, -1, -1 }, { 0, -1, -1 }, { 0, -1, -1 }, { 0, 2, -1 } };
     int first_space = -1;
-    std::vector<double> g_first(6, 0.0);
+    std::vector<double> g_first((size_t)h->restart_alloc + 3, 0.0);
     if (rec_on && stage > 0)
         for (int q = 0; q < stage && first_space < 0; q++) {
-            bool use = h->rec_mode == 2;
+            bool use = h->rec_mode == 2 || rec_full;
             for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
             if (use && h->rec[q].valid && h->rec[q].pc == pcmode) first_space = q;
         }
@@ -223,34 +229,36 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
     bool x0_pending = false;
     double *const Xbase = use_poly ? h->Zb : h->V;          // slot 0 of the basis the solution is expanded in
     const int xslot0 = use_poly ? zb : vb;                  // first slot of this solve's own vectors
+    bool pc_x0_pending = false;
+    double *const rbuf = (x == h->t3) ? V : h->t3;           // projected residual (a correction solve has its x in t3: this solve's slot 0 then, scaled in place below)
     if (rec_on && stage > 0) {
         int last_space = -1;                                  // its residual update also returns the norm of the result
         for (int q = 0; q < stage; q++) {
-            bool use = h->rec_mode == 2;
+            bool use = h->rec_mode == 2 || rec_full;
             for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
             if (use && h->rec[q].valid && h->rec[q].pc == pcmode) last_space = q;
         }
         bool have_norm = false;
         for (int q = 0; q < stage; q++) {
-            bool use = h->rec_mode == 2;
+            bool use = h->rec_mode == 2 || rec_full;
             for (int e = 0; e < 3; e++) use = use || sel[stage][e] == q;
             const ksfd_handle::RecSpace &S = h->rec[q];
             if (!use || !S.valid || S.pc != pcmode) continue;
             const double *Vs = h->V + (int64_t)S.vb * vs;
             const double *Zs = use_poly ? h->Zb + (int64_t)S.zb * vs : Vs;
-            double gq[5], yq[4], Hy[5], neg[5];
+            std::vector<double> gq_((size_t)S.k + 2), yq_((size_t)S.k + 1), Hy_((size_t)S.k + 2), neg_((size_t)S.k + 2);
+            double *gq = gq_.data(), *yq = yq_.data(), *Hy = Hy_.data(), *neg = neg_.data();
             if (q == first_space && rsrc == b) {
                 for (int i = 0; i <= S.k; i++) gq[i] = g_first[i];                 // already computed together with ||b||
             } else {
                 if ((rc = op_multidot(h, rsrc, Vs, S.k + 1))) return rc;
                 for (int i = 0; i <= S.k; i++) gq[i] = h->hres[i];
             }
-            hess_lsq(S.H, S.k, gq, yq, Hy);
+            hess_lsq(S.H.data(), S.k, gq, yq, Hy);
             if (use_pc) {
-                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, 0.0)) || (rc = mg_precond(h, shift_pc, h->t2, h->t1))) return rc;
-                if (!x_set) { if ((rc = op_copy(h, x, h->t1))) return rc; }
-                else { const double *xs[2] = { x, h->t1 }; double a2[2] = { 1.0, 1.0 }; if ((rc = op_lincomb(h, 2, xs, a2, x))) return rc; }
-                x_set = true;
+                // x0 = M^-1 (sum over the spaces of V_s y_s): the combinations gather in t2, one V cycle behind the loop
+                if ((rc = op_basis_axpy(h, h->t2, Vs, S.k, yq, pc_x0_pending ? 1.0 : 0.0))) return rc;
+                pc_x0_pending = true;
             } else if (defer_x0) {
                 for (int i = 0; i < S.k; i++) xcoef[(use_poly ? S.zb : S.vb) + i] += yq[i];
                 x0_pending = true;
@@ -259,13 +267,22 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
                 x_set = true;
             }
             for (int i = 0; i <= S.k; i++) neg[i] = -Hy[i];
-            if (rsrc == b) {
+            if (rsrc == b && S.k + 2 <= 6) {
                 const double *xs[6] = { b }; double a[6] = { 1.0 };
                 for (int i = 0; i <= S.k; i++) { xs[i + 1] = Vs + (int64_t)i * vs; a[i + 1] = neg[i]; }
-                if ((rc = op_lincomb(h, S.k + 2, xs, a, h->t3, q == last_space))) return rc;
-                rsrc = h->t3;
-            } else if ((rc = op_basis_axpy(h, h->t3, Vs, S.k + 1, neg, 1.0, q == last_space))) return rc;
-            have_norm = q == last_space;
+                if ((rc = op_lincomb(h, S.k + 2, xs, a, rbuf, q == last_space))) return rc;
+                rsrc = rbuf;
+                have_norm = q == last_space;
+            } else {
+                if (rsrc == b) { if ((rc = op_copy(h, rbuf, b))) return rc; rsrc = rbuf; }
+                const bool nrm = q == last_space;
+                if ((rc = op_basis_axpy(h, rbuf, Vs, S.k + 1, neg, 1.0, nrm))) return rc;
+                have_norm = nrm;
+            }
+        }
+        if (pc_x0_pending) {
+            if ((rc = mg_precond(h, shift_pc, h->t2, h->t1)) || (rc = op_copy(h, x, h->t1))) return rc;
+            x_set = true;
         }
         if (x_set || x0_pending) {
             if (!have_norm && (rc = op_multidot(h, rsrc, rsrc, 0))) return rc;
@@ -395,8 +412,9 @@ static int gmres(ksfd_handle *h, const double *ustate, double shift, const doubl
         if (rec_on && first && !restarted && done && j >= 1) {
             // keep the leading vectors of this stage's Arnoldi relation where they are; the next stage builds behind them
             ksfd_handle::RecSpace &S = h->rec[stage];
-            S.k = std::min(j, std::min(h->rec_keep, 4));
+            S.k = rec_full ? j : std::min(j, std::min(h->rec_keep, 4));
             S.vb = vb; S.zb = zb; S.pc = pcmode;
+            S.H.assign((size_t)(S.k + 1) * S.k, 0.0);
             for (int c = 0; c < S.k; c++)
                 for (int i = 0; i <= S.k; i++) S.H[c * (S.k + 1) + i] = Hraw[(size_t)(m + 1) * c + i];
             S.valid = true;

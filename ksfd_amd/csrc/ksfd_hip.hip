@@ -793,7 +793,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                 for (int j = 0; j < sg.n; j++) { xs[j] = sg.Y[j]; a[j] = sg.c[j]; }
                 if ((rc = op_lincomb(h, sg.n, xs, a, xi)) || (rc = halo(h, xi)) || (rc = op_jvp_frozen(h, xi, 2, shift, h->Z, bcur))) break;
                 const double tol = std::max(opts->ksp_rtol * sqrt(bnorm2), opts->ksp_atol);
-                rc = gmres(h, h->u, shift, h->Z, h->t3, opts, &ls, 1, -1, tol);
+                rc = gmres(h, h->u, shift, h->Z, h->t3, opts, &ls, 1, i, tol);        // stage index: the Krylov spaces of the earlier stages are projected out first
                 if (!rc) { const double *x2[2] = { xi, h->t3 }; double a2[2] = { 1.0, 1.0 }; rc = op_lincomb(h, 2, x2, a2, xi); }
                 st.pc_used |= 2;
             } else {
@@ -1021,6 +1021,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->restart_grow = !(use_fused & 131072);
         h->mg_warm_power = !(use_fused & 262144);
         h->mg_fp32 = !(use_fused & 524288);
+        h->rec_mg = (use_fused & 1048576) != 0;
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

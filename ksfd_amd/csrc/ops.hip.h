@@ -85,7 +85,9 @@ static KStrips make_strips(const ksfd_handle *h, bool jvp = false)
     // small grids: shorter segments so that there are enough waves to fill 256 CUs (a wave costs ~1 us per row it
     // marches; the 4 halo rows per segment are L2 hits at these sizes)
     {
-        const long long target = jvp ? 4096 : 6144;
+        static const long long t_jvp = getenv("KSFD_WAVES_JVP") ? atoll(getenv("KSFD_WAVES_JVP")) : 4096;       // experiments (tools/yseg_sweep.py)
+        static const long long t_rhs = getenv("KSFD_WAVES_RHS") ? atoll(getenv("KSFD_WAVES_RHS")) : 6144;
+        const long long target = jvp ? t_jvp : t_rhs;
         long long fit = (long long)S.nstrips * h->G.sloc / target;
         if (fit < 2) fit = 2;
         if (fit < S.yseg) S.yseg = (int)fit;
