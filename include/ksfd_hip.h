@@ -243,6 +243,8 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * the length, up to the 30 ... 120 basis vectors ksfd_create found room for);
  * bit18 set = every multigrid set-up estimates the Chebyshev bound of a level by a cold power iteration (default: warm start from the
  * vector of the previous set-up, at most three iterations);
+ * bit21 set = the inner products of a new stage right-hand side with the earlier ones (stage guesses) are a pass of their own instead of
+ * part of the RHS kernel's store epilogue;
  * bit20 set = multigrid-preconditioned stage solves keep the whole first GMRES cycle of every stage and project the later stages of the step
  * on it first (experiment, measured slower: krylov.hip.h);
  * bit19 set = the V cycle keeps its level vectors in fp64 at every tolerance (default: fp32 level vectors when ksp_rtol >= 1e-8, 2-D);

@@ -176,6 +176,7 @@ struct ksfd_handle {
     int rec_vtop = 0, rec_ztop = 0;  // first free slot of V / Zb behind the kept vectors
     int rec_mode = 1;                // 0 off, 1 selected earlier stages (default), 2 every earlier stage
     int rec_keep = 3;                // leading vectors kept per stage (<= 4)
+    bool rhs_dots = true;            // inner products for the stage guesses from the RHS kernel's store epilogue (KSFD_TUNE bit 21 clears)
     bool rec_mg = false;             // multigrid-preconditioned solves: the WHOLE first cycle of every stage is kept for the later stages of the step (KSFD_TUNE bit 20 sets; measured: no gain, see gmres)
 
     // multigrid preconditioner

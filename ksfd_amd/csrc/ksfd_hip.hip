@@ -699,6 +699,8 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         for (int i = 0; i < 4 && !rc; i++) {
             const double *zin = h->u;
             double bnorm2 = -1.0;                 // ||b||^2 when the RHS kernel's epilogue delivered it
+            bool rhs_dots_done = false;           // ... and <b_i, b_j> for the stage guess with it
+            double rhs_dot[2] = { 0.0, 0.0 };
             double *bcur = (guess_on && i < 3) ? h->bstore + (int64_t)i * vs : h->bvec;
             if (fuse_stage) {
                 // stage argument and Zdot term folded into the RHS kernel (no Z vector, no separate passes)
@@ -707,10 +709,16 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                     if (h->At[i][j] != 0.0) { cmb.yin[cmb.nin] = h->Y + (int64_t)j * vs; cmb.ain[cmb.nin++] = h->At[i][j]; }
                     if (h->Ginv[i][j] != 0.0) { cmb.yout[cmb.nout] = h->Y + (int64_t)j * vs; cmb.aout[cmb.nout++] = -h->Ginv[i][j] / hh; }
                 }
-                const bool rhs_norm = use_spec && fused_ok(h) && !(guess_on && i > 0);      // ||b||^2 from the store epilogue (2-D strip kernel)
+                // ||b||^2 from the store epilogue (2-D strip kernel), and with it the inner products of b_i with the right-hand sides the stage
+                // guess is built from (the multi-dot below would read all of them again)
+                const int gdot_j0 = std::max(0, i - h->guess_max), gdot_n = (guess_on && i > 0 && h->rhs_dots) ? i - gdot_j0 : 0;
+                const bool rhs_norm = use_spec && fused_ok(h) && (!(guess_on && i > 0) || (gdot_n > 0 && gdot_n <= 2 && (long long)make_strips(h).nstrips * make_strips(h).nseg * (1 + gdot_n) <= part_capacity()));
+                rhs_dots_done = rhs_norm && gdot_n > 0;
                 // ghosts of the newest stage vector (earlier ones done): exchanged behind the interior rows of the RHS (op_rhs)
-                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, rhs_norm, i > 0 ? h->Y + (int64_t)(i - 1) * vs : nullptr))) break;
+                if ((rc = op_rhs(h, h->u, i, bcur, &cmb, rhs_norm, i > 0 ? h->Y + (int64_t)(i - 1) * vs : nullptr, rhs_dots_done ? gdot_n : 0,
+                                 rhs_dots_done ? h->bstore + (int64_t)gdot_j0 * vs : nullptr))) break;
                 if (rhs_norm) bnorm2 = h->hres[0];
+                if (rhs_dots_done) for (int j = 0; j < gdot_n; j++) rhs_dot[j] = h->hres[1 + j];
             } else {
             if (i > 0) {
                 const double *xs[5]; double a[5]; int nt = 0;
@@ -744,9 +752,14 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
                         // j0 > 0 (h->guess_max): only the most recent stages enter -- every vector of the guess costs two more full-vector
                         // reads in the first sweep (b_j in the forward row kernel, Y_j in the inverse one) and one in this multi-dot
                         const int j0 = std::max(0, i - h->guess_max), ng = i - j0;
-                        if ((rc = op_multidot(h, bcur, h->bstore + (int64_t)j0 * vs, ng))) break;
-                        for (int j = 0; j < ng; j++) gb[i][j0 + j] = gb[j0 + j][i] = h->hres[j];
-                        gb[i][i] = bnorm2 = h->hres[ng];
+                        if (rhs_dots_done) {
+                            for (int j = 0; j < ng; j++) gb[i][j0 + j] = gb[j0 + j][i] = rhs_dot[j];
+                            gb[i][i] = bnorm2;
+                        } else {
+                            if ((rc = op_multidot(h, bcur, h->bstore + (int64_t)j0 * vs, ng))) break;
+                            for (int j = 0; j < ng; j++) gb[i][j0 + j] = gb[j0 + j][i] = h->hres[j];
+                            gb[i][i] = bnorm2 = h->hres[ng];
+                        }
                         double M[3][4];
                         for (int a = 0; a < ng; a++) { for (int c = 0; c < ng; c++) M[a][c] = gb[j0 + a][j0 + c]; M[a][ng] = gb[i][j0 + a]; M[a][a] *= 1.0 + 1e-13; }
                         bool okls = ng > 0;
@@ -1022,6 +1035,7 @@ extern "C" int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg, 
         h->mg_warm_power = !(use_fused & 262144);
         h->mg_fp32 = !(use_fused & 524288);
         h->rec_mg = (use_fused & 1048576) != 0;
+        h->rhs_dots = !(use_fused & 2097152);
         if (h->mg_fuse != !(use_fused & 4096)) { h->mg_fuse = !(use_fused & 4096); h->mg_shift = -1.0; if (h->mg_graph) { hipGraphExecDestroy(h->mg_graph); h->mg_graph = nullptr; } }
     }
     if (yseg > 0) h->yseg = yseg;

@@ -197,7 +197,9 @@ static inline long long part_capacity() { return (long long)(2 * KSFD_MAXDOT + 4
 // halo_vec (slab ranks): a vector among the inputs whose ghost rows have NOT been exchanged yet (the newest stage vector).  On the
 // 2-D strip path they travel on the communication stream while the interior segments are computed -- the scheme of
 // op_jvp_frozen_halo: only the first and the last segment read ghost rows -- elsewhere they are exchanged first.
-static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr, bool want_norm = false, double *halo_vec = nullptr)
+// ndots (with want_norm, fused 2-D path): <out, dotv + q*vlen>, q < ndots <= 2, land in h->hres[1 + q] beside ||out||^2 in h->hres[0]
+static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const KComb *cmb = nullptr, bool want_norm = false, double *halo_vec = nullptr,
+                  int ndots = 0, const double *dotv = nullptr)
 {
     const KGeom &G = h->G;
     KSrc S = src_of(h, stage);
@@ -208,14 +210,16 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         KStrips K = make_strips(h);
         KComb C = cmb ? *cmb : KComb{};
         const long long nwaves = (long long)K.nstrips * K.nseg;
-        const bool fused_norm = want_norm && nwaves <= part_capacity();
+        const bool fused_norm = want_norm && nwaves * (1 + ndots) <= part_capacity();
+        KDots D = KDots{};
+        if (fused_norm && ndots > 0) { D.n = std::min(ndots, 2); D.stride = nwaves; for (int q = 0; q < D.n; q++) D.v[q] = dotv + (int64_t)q * h->vlen; }
         // the vectors added at the store are the ones the stage argument is formed from: one read serves both (k_rhs2d_fused<NL, true>)
         bool carry = h->rhs_carry && C.nout > 0 && C.nout == C.nin;
         for (int j = 0; j < C.nout && carry; j++) carry = C.yin[j] == C.yout[j];
         auto launch = [&](const KStrips &Kx, double frac, double *np) {
-            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + (carry ? 0 : C.nout)) * frac, vbytes(h, 2 + C.nin + C.nout) * frac);
-            if (carry) { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL, true>), dim3(Kx.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, Kx, u, S, out, C, np)); }
-            else { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(Kx.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, Kx, u, S, out, C, np)); }
+            Scope sc(h, KC_RHS, vbytes(h, 2 + C.nin + (carry ? 0 : C.nout) + D.n) * frac, vbytes(h, 2 + C.nin + C.nout + D.n) * frac);
+            if (carry) { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL, true>), dim3(Kx.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, Kx, u, S, out, C, np, D)); }
+            else { NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs2d_fused<NL>), dim3(Kx.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, Kx, u, S, out, C, np, D)); }
         };
         double *np = fused_norm ? h->part : (double *)nullptr;
         const bool ovl = halo_vec && h->overlap && K.nseg >= 3;
@@ -242,7 +246,7 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
             launch(Kb, 2.0 / K.nseg, np ? np + (long long)K.nstrips * (K.nseg - 2) : nullptr);
         }
         HIPCHK(h, hipGetLastError());
-        if (fused_norm) return reduce_rows(h, 1, (int)nwaves, 0);
+        if (fused_norm) return reduce_rows(h, 1 + D.n, (int)nwaves, 0);
         if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm needs the strip kernels");
         return KSFD_OK;
     }

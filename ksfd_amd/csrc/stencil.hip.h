@@ -26,6 +26,15 @@ struct KComb {
     double ain[3], aout[3];
 };
 
+// Inner products of what the RHS kernel stores with up to two given vectors (ghosted layout), from the same store epilogue as ||out||^2:
+// wave w leaves <out, v[q]> in normpart[(1 + q) * stride + w].  The stage guesses of ksfd_step need <b_i, b_j> of the new right-hand
+// side with the two before it; as a pass of their own they cost a read of all three vectors.
+struct KDots {
+    int n;
+    long long stride;
+    const double *v[2];
+};
+
 // Smoother algebra of the multigrid preconditioner folded into the Jacobian-action epilogue (modes 5 and 6):
 //   5:  r = yadd - A v  -> out ;  d = scale * Dinv r -> out2                (residual + first Chebyshev direction)
 //   6:  x = (x_has_d ? d : x + d) + c1*d + c2 * Dinv (rr - A d),  v = d     (k_cheb_last without the A d round trip; x_has_d: first sweep
@@ -556,13 +565,13 @@ __device__ __forceinline__ KWaveJob ksfd_wave_job(const KGeom &G, const KStrips 
 template <int NL, bool CARRY = false>
 __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KStrips S, const double *__restrict__ u,
                                                             KSrc src, double *__restrict__ out, KComb cmb = KComb{},
-                                                            double *__restrict__ normpart = nullptr)
+                                                            double *__restrict__ normpart = nullptr, KDots dots = KDots{})
 {
     // normpart != NULL: every wave also leaves the sum of squares of what it stored in normpart[wave id] (||out||^2 without
-    // a pass of its own; finished by k_reduce_rows in a fixed order)
+    // a pass of its own; finished by k_reduce_rows in a fixed order), and its share of the inner products `dots` asks for
     const KWaveJob J = ksfd_wave_job(G, S);
     if (!J.valid) return;                       // whole waves only; the kernel has no block barrier
-    double nacc = 0.0;
+    double nacc = 0.0, dacc[2] = { 0.0, 0.0 };
     // 5-row windows, two columns per lane: slot s <-> row (r - 2 + s)
     double rw[5][2], gw[5][2], uw[NL][5][2];
     double nr[2], nu[NL][2];                   // raw values of the row being prefetched
@@ -672,12 +681,19 @@ __global__ void __launch_bounds__(KSFD_BLOCK) k_rhs2d_fused(KGeom G, KPhys P, KS
                 }
                 ksfd_st2(out + (long long)c * G.plane + o, a, b);
                 nacc += a * a + b * b;
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    if (q < dots.n) { const double2 y = ksfd_ld2(dots.v[q] + (long long)c * G.plane + o); dacc[q] += a * y.x + b * y.y; }
             }
         }
     }
     if (normpart) {
         nacc = ksfd_wave_sum(nacc);
         if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) normpart[J.wid] = nacc;
+        for (int q = 0; q < dots.n; q++) {
+            const double t = ksfd_wave_sum(dacc[q]);
+            if ((threadIdx.x & (KSFD_WAVE - 1)) == 0) normpart[(long long)(1 + q) * dots.stride + J.wid] = t;
+        }
     }
 }
 
