@@ -79,3 +79,18 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     assert 'class1=jvp rtol=1e-06 pc=2' in r.stdout and 'rc=1' in r.stdout and 'dim must be' in r.stdout
+
+
+def test_live_pmc_of_the_bench_never_raises_without_a_gpu():
+    """bench.py measures roofline.traffic in two rocprofv3 --pmc child runs of itself; whatever goes wrong there (no profiler, no GPU, a
+    crash of the child) must come back as (None, reason) -- the bench line then falls back to the committed summary and says so."""
+    import argparse
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench
+    args = argparse.Namespace(n=64, nlig=1, dim=2)
+    val, err = bench.live_pmc(args, 'spectral')
+    assert val is None and isinstance(err, str) and err
+    val, err = bench.live_pmc(args, 'no-such-class')
+    assert val is None and 'pattern' in err

@@ -288,3 +288,33 @@ print('RESULT', pa, ra, pb, rb, abs(ta - tb) / tb, float(np.linalg.norm(a - b) /
     assert res < res_v                                     # ... and they are what saves residual evaluations
     assert r.stderr.count('predicted final sweep') == pred
     assert dt < 1e-6 and err < 1e-9
+
+
+@pytest.mark.parametrize('shape,nlig', [((128, 96), 1), ((64, 64), 2), ((96, 48), 1)])
+def test_guess_inner_products_from_the_rhs_epilogue(shape, nlig):
+    """The stage guesses need <b_i, b_j> of a new stage right-hand side with the (up to two) before it.  They come out of the RHS kernel's
+    store epilogue (per-wave partials beside ||b_i||^2); KSFD_TUNE bit 21 computes them in a pass of their own as before: same sweeps, same
+    accepted steps, step sizes and states equal to what the rounding of the sums does to the guesses (1e-9 / 1e-10: the solves stop at 1e-6),
+    fewer launches."""
+    cfg = ProblemConfig.standard(2, shape, L=tuple(n * 4.0 / 1536 for n in shape), nlig=nlig)
+    rng = np.random.default_rng(7)
+    rho = 9000 + 90 * rng.standard_normal(cfg.N)
+    u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(nlig)])
+    out = {}
+    for name, tune in (('epilogue', 1), ('own pass', 1 | 2097152)):
+        k = klib.KSFDHip(cfg)
+        k.set_tuning(use_fused=tune)
+        k.set_state(u)
+        o = klib.default_step_opts(adapt=1, atol=0.01, rtol=1e-6, pc_type=4)
+        t, h, its, launches = 0.0, 0.05, 0, 0
+        for _ in range(4):
+            t, h, st, rc = k.step(t, h, o)
+            assert st.pc_used & 8
+            its += st.linear_its
+            launches += st.launches
+        out[name] = (t, its, launches, k.get_state())
+        k.close()
+    a, b = out['epilogue'], out['own pass']
+    assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-9 * abs(b[0])
+    assert a[2] < b[2]
+    assert rel_l2(a[3], b[3]) < 1e-10
