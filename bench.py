@@ -67,6 +67,7 @@ def parse_args(argv=None):
                     help='torch.distributed backend for launch/timing; gloo + --transport host lets several ranks share one GPU (rehearsal)')
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal: every rank uses device 0')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-autotune', action='store_true', help='N > 1: keep the library\'s default stage solver instead of timing the window with and without the distributed spectral solver')
     ap.add_argument('--no-live-pmc', action='store_true', help='take roofline.traffic from the committed PMC summary instead of measuring it in two rocprofv3 child runs')
     ap.add_argument('--cpu-sample-n', type=int, default=1024)
     ap.add_argument('--cpu-lu-n', type=int, default=256, help='grid of the sparse-LU CPU baseline (0 skips it); SuperLU needs ~15 s at 256^2, > 80 s at 512^2')
@@ -261,6 +262,31 @@ def main():
                 tally.add(st)
         return t
 
+    # ---------------- N > 1: which stage solver for THIS interconnect?  The slab-distributed spectral solver moves the whole work array
+    # through two all-to-alls per sweep (24 per step); polynomially preconditioned GMRES only exchanges ghost rows.  Which one is faster
+    # depends on the links between the devices, so both walk the window once (after a warm-up walk each) and the faster one stays.
+    # Same tolerance and stopping test either way; the line reports both times and what ran (steps_by_solver).
+    autotune = None
+    rehearse = bool(os.environ.get('KSFD_BENCH_AUTOTUNE'))     # rehearsal on a shared GPU (host transport: open_handle keeps the spectral solver off there)
+    if rehearse and world > 1:
+        ks.set_spectral_params(enable=1)
+    if world > 1 and args.pc_type < 0 and not args.no_autotune and (getattr(ks, 'spectral_distributed', False) or rehearse):
+        def timed_walk():
+            walk(args.window)
+            barrier()
+            t0_ = time.perf_counter()
+            walk(args.window)
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0_) / args.window
+        ms_spec = 1e3 * timed_walk()
+        ks.set_spectral_params(enable=0)
+        ms_alt = 1e3 * timed_walk()
+        keep_spectral = ms_spec <= ms_alt                      # max over ranks: the same decision everywhere
+        if keep_spectral:
+            ks.set_spectral_params(enable=1)
+        autotune = {'spectral_ms_per_step': ms_spec, 'without_spectral_ms_per_step': ms_alt, 'chosen': 'spectral' if keep_spectral else 'gmres (polynomial / multigrid)'}
+        ks.restore()
+
     ks.set_profiling(True)
     ks.profile(reset=True)
     walk(args.warmup)
@@ -330,7 +356,7 @@ def main():
                              't_star': t_star, 'h_star': h_star, 'window': args.window, 't_end_of_window': t_last,
                              'parallelism': 'slab%d' % world, 'transport': getattr(ks, 'transport_name', 'none'),
                              'rccl_error': getattr(ks, 'rccl_error', None),
-                             'spectral_distributed': getattr(ks, 'spectral_distributed', None)}, **tal.summary()),
+                             'spectral_distributed': getattr(ks, 'spectral_distributed', None), 'solver_autotune': autotune}, **tal.summary()),
             'roofline': {'bound': 'hbm', 'kernel': dom,
                          # `achieved`/`frac`: ALGORITHMIC bytes per launch (Jacobian action 24*F*N) / HIP-event time per launch
                          'achieved': gbs(alg_bytes), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs(alg_bytes) / HBM_PEAK_GBS,

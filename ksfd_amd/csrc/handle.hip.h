@@ -56,6 +56,7 @@ struct SpecState {
     double a_rr = 0.0, a_rU[KSFD_MAXL] = { 0 };
     // adaptation: steps (counted by ksfd_step calls) before which the automatic choice leaves it alone after it converged badly
     long long bad_until = 0;
+    bool user_off = false;                   // ksfd_set_spectral_params(enable = 0): off until enabled again; a checkpoint restore does not bring it back
     int backoff = 8;
     // largest contraction ||r_k+1|| / ||r_k|| of a defect-correction sweep measured in the current / the previous step
     // (spec_solve: predicted last sweep)

@@ -656,7 +656,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const double mg_from = h->mg_threshold * ((double)h->G.F * (double)h->G.nloc < 8.0e6 ? 3.0 : 1.0);
         // spectral preconditioner (constant-coefficient part of shift*I - J inverted by FFT): nearly exact while the state is a
         // smooth perturbation of a uniform one, at any stiffness; pc_type 2 uses it until it converges badly (see below), 4 always
-        bool use_spec = h->spec.ok && h->use_frozen && (opts->pc_type == 4 || (opts->pc_type == 2 && stiff >= (fused_ok(h) ? h->spec_from : std::max(h->spec_from, 0.3)) && h->nsteps > h->spec.bad_until));      // (without the fused 2-D residual kernel a sweep costs more: 3-D at X = 0.29, 80 ms plain GMRES against 83 ms)
+        bool use_spec = h->spec.ok && h->use_frozen && (opts->pc_type == 4 || (opts->pc_type == 2 && stiff >= (fused_ok(h) ? h->spec_from : std::max(h->spec_from, 0.3)) && h->nsteps > h->spec.bad_until && !h->spec.user_off));      // (without the fused 2-D residual kernel a sweep costs more: 3-D at X = 0.29, 80 ms plain GMRES against 83 ms)
         if (use_spec) {
             if (!h->Zb && alloc_d(h, &h->Zb, (int64_t)h->restart_alloc * h->vlen)) { rc = KSFD_ENOMEM; goto out; }
             if (!h->spec.means_valid && (rc = spec_means(h))) goto out;
@@ -1005,8 +1005,8 @@ extern "C" int ksfd_set_spectral_params(ksfd_handle *h, double from_stiffness, i
 {
     if (!h) return KSFD_EINVAL;
     if (from_stiffness > 0.0) h->spec_from = from_stiffness;
-    if (enable == 0) h->spec.bad_until = (1LL << 62);
-    else if (enable > 0) { h->spec.bad_until = 0; h->spec.backoff = 8; }
+    if (enable == 0) h->spec.user_off = true;
+    else if (enable > 0) { h->spec.user_off = false; h->spec.bad_until = 0; h->spec.backoff = 8; }
     return KSFD_OK;
 }
 extern "C" int ksfd_synchronize(ksfd_handle *h)
