@@ -875,14 +875,23 @@ __global__ void __launch_bounds__(1024) k_spec3_y_fwd(KFFTPlan PY, int nx, int n
     const long long ntiles = ((long long)ny * nz) >> lg_rb;
     const int nseq = npair * cz;
     // sequence s = p*cz + zc ; element y
-    kspec_stage_in<kcf>(nseq * ny, [&](int idx) {
-        const int s = idx >> lg_ny, y = idx & (ny - 1);
+    auto gather = [&](int s, int y) {
         const int p = s >> lg_cz, zc = s & (cz - 1);
         const long long R = (long long)(z0 + zc) * ny + y;
         return Wt[(((long long)p * ntiles + (R >> lg_rb)) * nx + jx) * rb + (R & (rb - 1))];
-    }, [&](int idx, kcf v) { kspec_lds[(idx >> lg_ny) * sstride + kspec_pad(idx & (ny - 1))] = v; });
-    __syncthreads();
-    kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
+    };
+    if (PY.m == 1 && PY.radix[0] == 16 && (PY.flags & 1)) {
+        // first stage on the gathered values themselves (the 16 loads of a thread in flight together, no staging pass: as k_spec_cols)
+        const int S0 = ny >> 4;
+        kspec_stage0_fwd_from(kspec_lds, sstride, nseq, lg_ny, tw, [&](int s, int i, int q) { return gather(s, i + q * S0); });
+        __syncthreads();
+        kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw, 1);
+    } else {
+        kspec_stage_in<kcf>(nseq * ny, [&](int idx) { return gather(idx >> lg_ny, idx & (ny - 1)); },
+                            [&](int idx, kcf v) { kspec_lds[(idx >> lg_ny) * sstride + kspec_pad(idx & (ny - 1))] = v; });
+        __syncthreads();
+        kspec_fft_fwd(PY, kspec_lds, sstride, nseq, tw);
+    }
     for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
         const int zc = idx & (cz - 1), rest = idx >> lg_cz;
         const int jy = rest & (ny - 1), p = rest >> lg_ny;
@@ -907,8 +916,20 @@ __global__ void __launch_bounds__(1024) k_spec3_y_inv(KFFTPlan PY, int nx, int n
         kspec_lds[(p * cz + zc) * sstride + kspec_pad(jy)] = v;
     });
     __syncthreads();
-    kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     const long long nrows = (long long)ny * nz;
+    if (PY.m == 1 && PY.radix[0] == 16 && (PY.flags & 2)) {
+        // last stage of the inverse straight into the store (runs of consecutive y per lane group)
+        kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw, 1);
+        const int S0 = ny >> 4;
+        kspec_stage0_inv_to(kspec_lds, sstride, nseq, lg_ny, tw, [&](int s, int i, kcf (&x)[16]) {
+            const int p = s >> lg_cz, zc = s & (cz - 1);
+            kcf *dst = W3 + ((long long)p * nx + jx) * nrows + (long long)(z0 + zc) * ny + i;
+#pragma unroll
+            for (int q = 0; q < 16; q++) dst[q * S0] = x[q];
+        });
+        return;
+    }
+    kspec_fft_inv(PY, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * ny; idx += blockDim.x) {
         const int s = idx >> lg_ny, y = idx & (ny - 1);
         const int p = s >> lg_cz, zc = s & (cz - 1);
@@ -966,6 +987,13 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
         return W2 + (((long long)p * ncol + (c ? pt.y : pt.x)) << lg_pl);
     };
     auto zoff = [&](int z) { return (long long)(z >> lg_pl) * pstride + (z & plmask); };      // z even: a float4 never straddles two pieces
+    const bool edge_in = PZ.m == 1 && PZ.radix[0] == 16 && (PZ.flags & 1), edge_out = PZ.m == 1 && PZ.radix[0] == 16 && (PZ.flags & 2);
+    const int S0 = nz >> 4;
+    if (edge_in) {
+        kspec_stage0_fwd_from(kspec_lds, sstride, nseq, PZ.lg, tw, [&](int s, int i, int q) { return colptr(s)[zoff(i + q * S0)]; });
+        __syncthreads();
+        kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw, 1);
+    } else {
     kspec_stage_in<float4>(nseq * half, [&](int idx) {
         const int s = idx >> lg_half, z = 2 * (idx & (half - 1));
         return *reinterpret_cast<const float4 *>(colptr(s) + zoff(z));
@@ -977,12 +1005,23 @@ __global__ void __launch_bounds__(1024) k_spec3_z(KFFTPlan PZ, int nent, int pb,
     });
     __syncthreads();
     kspec_fft_fwd(PZ, kspec_lds, sstride, nseq, tw);
+    }
     if (NPAIR_T == 1) kspec3_z_symbol<1>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S);
     else if (NPAIR_T == 2) {
         if (S.nlig == 2) kspec3_z_symbol<2>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S);
         else kspec3_z_symbol<3>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S);
     } else { KSPEC_NL_SWITCH(S.nlig, (kspec3_z_symbol<NL>(PZ, kspec_lds, sstride, ne, e0, pairtab, posz, kzofpos, lx, ly, lz, ztab, S))); }
     __syncthreads();
+    if (edge_out) {
+        kspec_fft_inv(PZ, kspec_lds, sstride, nseq, tw, 1);
+        kspec_stage0_inv_to(kspec_lds, sstride, nseq, PZ.lg, tw, [&](int s, int i, kcf (&x)[16]) {
+            if ((s & 1) && pairtab[e0 + (s >> 1) / npair].w) return;       // the B slot of a self column is a copy
+            kcf *dst = colptr(s);
+#pragma unroll
+            for (int q = 0; q < 16; q++) dst[zoff(i + q * S0)] = x[q];
+        });
+        return;
+    }
     kspec_fft_inv(PZ, kspec_lds, sstride, nseq, tw);
     for (int idx = threadIdx.x; idx < nseq * half; idx += blockDim.x) {
         const int s = idx >> lg_half, z = 2 * (idx & (half - 1));

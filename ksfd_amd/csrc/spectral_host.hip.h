@@ -329,9 +329,13 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         const int thr_y = (int)std::min<long long>(1024, std::max<long long>(256, (long long)S.npair * cz * G.ny / 16));
         int thr_z = (int)std::min<long long>(1024, std::max<long long>(128, (long long)2 * S.npair * S.pb * nzg / 16));
         if (getenv("KSFD_SPEC_THRZ")) thr_z = atoi(getenv("KSFD_SPEC_THRZ"));
+        // fused edge stages of the y and z kernels (bit 0: first forward stage on the loaded values, bit 1: last inverse stage into the store)
+        static const int fuse3 = getenv("KSFD_SPEC_FUSE3") ? atoi(getenv("KSFD_SPEC_FUSE3")) : 3;
+        KFFTPlan py3 = S.py, pz3 = S.pz;
+        py3.flags = pz3.flags = fuse3 & 3;
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
-            hipLaunchKernelGGL(k_spec3_y_fwd, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)nzl, S.lg_cz, S.npair, S.lg_rb3,
+            hipLaunchKernelGGL(k_spec3_y_fwd, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, py3, (int)G.nx, (int)nzl, S.lg_cz, S.npair, S.lg_rb3,
                                (const kcf *)S.W2, S.W, (const kcf *)S.twy);
         }
         kcf *Wz = S.W;
@@ -343,7 +347,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
             const long long pstride = (long long)S.npair * S.nxl * G.ny << S.lg_pl;
-#define KSPEC_Z_LAUNCH(NP) hipLaunchKernelGGL(k_spec3_z<NP>, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, S.pz, S.nent, S.pb, (long long)S.nxl * G.ny, S.lg_pl, pstride, Wz, \
+#define KSPEC_Z_LAUNCH(NP) hipLaunchKernelGGL(k_spec3_z<NP>, dim3((unsigned)((S.nent + S.pb - 1) / S.pb)), dim3(thr_z), S.lds_z3, h->st, pz3, S.nent, S.pb, (long long)S.nxl * G.ny, S.lg_pl, pstride, Wz, \
                                (const kcf *)S.twz, (const int4 *)S.pairtab, (const int *)S.posz, (const int *)S.kzofpos, (const float *)S.lx, (const float *)S.ly, (const float *)S.lz, (const int2 *)S.ytab, Y)
             if (S.npair == 1) KSPEC_Z_LAUNCH(1); else if (S.npair == 2) KSPEC_Z_LAUNCH(2); else KSPEC_Z_LAUNCH(0);
 #undef KSPEC_Z_LAUNCH
@@ -354,7 +358,7 @@ static int spec_apply(ksfd_handle *h, double shift, const double *v, double *z, 
         }
         {
             Scope sc(h, KC_SPECTRAL, 2.0 * pn, 0.0);
-            hipLaunchKernelGGL(k_spec3_y_inv, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, S.py, (int)G.nx, (int)nzl, S.lg_cz, S.npair,
+            hipLaunchKernelGGL(k_spec3_y_inv, dim3((unsigned)(nzl / cz), (unsigned)G.nx), dim3(thr_y), S.lds_y3, h->st, py3, (int)G.nx, (int)nzl, S.lg_cz, S.npair,
                                (const kcf *)S.W, S.W2, (const kcf *)S.twy);
         }
         // the inverse x rows read W3 = S.W2 ([pair][pos_x][z*ny + y]) below
