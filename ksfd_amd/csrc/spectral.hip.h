@@ -799,6 +799,26 @@ __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY
     auto colat = [&](kcf *base, int c, int y) {                // y even: a float4 never straddles two pieces
         return base + (long long)(y >> lg_pl) * pstride + (((long long)p0 * nxl + (c ? jB : jA)) << lg_pl) + (y & plmask);
     };
+    // fused edge stages as in k_spec_cols: phase 1 does the first forward stage on the values as they are gathered, phase 2 the last
+    // inverse stage straight into the store (PY.flags bits 0 / 1)
+    const bool edge = PY.m == 1 && PY.nstage > 0 && PY.radix[0] == 16;
+    const int S0 = ny >> 4;
+    if (phase == 1 && edge && (PY.flags & 1)) {
+        kspec_stage0_fwd_from(kspec_lds, sstride, ncol, PY.lg, tw, [&](int cl, int i, int q) {
+            const int c = c0 + cl, y = i + q * S0;
+            return lg_rb >= 0 ? Wt[(long long)p0 * nxl * ny + kspec_wt_index(PY.lgw, lg_rb, ny >> lg_rb, nxl, y >> lg_rb, c ? jB : jA, y & ((1 << lg_rb) - 1))]
+                              : *colat(W, c, y);
+        });
+        __syncthreads();
+        kspec_fft_fwd(PY, kspec_lds, sstride, ncol, tw, 1);
+        for (int idx = threadIdx.x; idx < ncol * half; idx += blockDim.x) {
+            const int cl = idx >> lg_half, y = 2 * (idx & (half - 1));
+            const kcf *q = kspec_lds + cl * sstride;
+            const kcf c0v = q[kspec_pad(y)], c1v = q[kspec_pad(y + 1)];
+            *reinterpret_cast<float4 *>(colat(W, c0 + cl, y)) = make_float4(c0v.x, c0v.y, c1v.x, c1v.y);
+        }
+        return;
+    }
     // both phases start by filling the LDS with the block's column(s)
     for (int base = 0; base < ncol * half; base += 8 * blockDim.x) {
         float4 t[8];
@@ -830,6 +850,14 @@ __global__ void __launch_bounds__(1024) k_spec_cols_split(int phase, KFFTPlan PY
         if (one) { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol_split1<NL>(PY, kspec_lds, self, c0, kxA, kxB, p0, W, nxl, lg_pl, pstride, jA, jB, posy, kyofpos, lx, ly, S))); }
         else { KSPEC_NL_SWITCH(S.nlig, (kspec_cols_symbol_split<NL>(PY, kspec_lds, sstride, self, kxA, kxB, p0, W, nxl, lg_pl, pstride, jA, jB, posy, kyofpos, lx, ly, S))); }
         __syncthreads();
+        if (edge && (PY.flags & 2)) {
+            kspec_fft_inv(PY, kspec_lds, sstride, ncol, tw, 1);
+            kspec_stage0_inv_to(kspec_lds, sstride, ncol, PY.lg, tw, [&](int cl, int i, kcf (&x)[16]) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) *colat(Wout, c0 + cl, i + q * S0) = x[q];
+            });
+            return;
+        }
         kspec_fft_inv(PY, kspec_lds, sstride, ncol, tw);
         dst = Wout;
     }
