@@ -247,7 +247,7 @@ int ksfd_bench_kernel(ksfd_handle *h, int32_t cls, int32_t reps, double *avg_ms,
  * part of the RHS kernel's store epilogue;
  * bit20 set = multigrid-preconditioned stage solves keep the whole first GMRES cycle of every stage and project the later stages of the step
  * on it first (experiment, measured slower: krylov.hip.h);
- * bit19 set = the V cycle keeps its level vectors in fp64 at every tolerance (default: fp32 level vectors when ksp_rtol >= 1e-8, 2-D);
+ * bit19 set = the V cycle keeps its level vectors in fp64 at every tolerance (default: fp32 level vectors when ksp_rtol >= 1e-7, 2-D);
  * yseg_*: rows per wave segment; <=0 keeps */
 int ksfd_set_tuning(ksfd_handle *h, int32_t use_fused, int32_t yseg_rhs, int32_t yseg_jvp);
 /* multigrid knobs (<=0 keeps): smoothing sweeps per side, cap on coarsest-grid sweeps, power iterations for the

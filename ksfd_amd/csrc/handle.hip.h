@@ -188,7 +188,7 @@ struct ksfd_handle {
     bool sf_tried_down = false, sf_auto = true;
     double sf_prev_its = 0.0, sf_prev_floor = 0.0;
     bool mg_fp32 = true;         // V cycle with fp32 level vectors when the solve tolerance allows (KSFD_TUNE bit 19 clears); see mg_vcycle32
-    bool mg_use32 = false;       // ... decided per step by ksfd_step (ksp_rtol >= 1e-8)
+    bool mg_use32 = false;       // ... decided per step by ksfd_step (ksp_rtol >= 1e-7)
     bool mg_graph_f32 = false;   // precision the captured coarse cycle was recorded in
     bool mg_warm_power = true;   // power iteration of a level starts from the vector of the previous set-up (KSFD_TUNE bit 18 clears)
     bool mg_fuse = true;         // smoother algebra inside the Jacobian-action epilogues (modes 5/6)

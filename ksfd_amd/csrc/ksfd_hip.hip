@@ -686,7 +686,7 @@ extern "C" int ksfd_step(ksfd_handle *h, double *t, double *hstep, const ksfd_st
         const bool use_async = !use_spec && !use_pc && !use_poly && h->use_frozen && !(opts->reserved & 1) && stiff >= 1e-3 &&
                                (!h->ring || h->tr->device_allreduce()) &&
                                (h->async_mode == 1 || (h->async_mode == 2 && small));
-        h->mg_use32 = opts->ksp_rtol >= 1e-8;          // fp32 level vectors inside the V cycle (mg_vcycle32); tight tolerances keep fp64
+        h->mg_use32 = opts->ksp_rtol >= 1e-7;          // fp32 level vectors inside the V cycle (mg_vcycle32); tight tolerances keep fp64
         const bool fuse_stage = (fused_ok(h) || (strip3d_ok(h) && h->rhs3d_strip)) && h->P.nlig <= 4 && h->fuse_stage;
         const int its_before = st.linear_its;
         bool spec_failed = false;

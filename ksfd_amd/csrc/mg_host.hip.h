@@ -436,7 +436,7 @@ static int mg_vcycle(ksfd_handle *h, size_t l, double shift, const double *b, do
 // The same V(2,2) cycle with fp32 LEVEL VECTORS (x, b, r, d of every f32 level; the arithmetic inside the kernels stays fp64).
 // A V cycle is a preconditioner: GMRES sees the true fp64 residual of the real system whatever the cycle returns, and the cycle is
 // bandwidth-bound -- at 4096^2 x 3 fields an iteration moves ~82 planes of 134 MB through level 0 alone, two thirds of them level
-// vectors.  Used when the step's ksp_rtol >= 1e-8 (ksfd_step; the parity tests at 1e-11 keep the fp64 cycle), 2-D, one rank or slab
+// vectors.  Used when the step's ksp_rtol >= 1e-7 (ksfd_step; the parity tests at 1e-11 keep the fp64 cycle), 2-D, one rank or slab
 // ranks (a float plane travels through the double-typed transport as half as many doubles), V(2,2) with the fused smoother.  The fp64 right-hand side is read once (k_dinv_apply leaves its fp32 copy), the last smoothing
 // kernel writes the result in fp64 (KSmoothT::x64); levels below the last f32 one run the fp64 code above, the transfer kernels
 // convert at that border.

@@ -408,7 +408,7 @@ def test_fused_multigrid_smoother_gives_the_same_iterates(shape):
 
 @pytest.mark.parametrize('shape,nlig', [((32, 32), 2), ((64, 48), 1), ((96, 64), 3), ((64, 64), 4), ((36, 36), 2), ((256, 32), 1)])
 def test_multigrid_cycle_with_fp32_level_vectors(shape, nlig):
-    """ksp_rtol >= 1e-8: the V cycle keeps its level vectors in fp32 (mg_vcycle32; arithmetic fp64, GMRES and its true-residual test fp64).
+    """ksp_rtol >= 1e-7: the V cycle keeps its level vectors in fp32 (mg_vcycle32; arithmetic fp64, GMRES and its true-residual test fp64).
     Same step as with the fp64 cycle (KSFD_TUNE bit 19) to the solve tolerance, iteration counts within one per stage, and (32^2, where the
     sparse LU takes seconds) the oracle's LU step to 5e-6 -- one to four ligands, a grid whose second level is already the coarsest one (36^2: only level 0 runs in fp32), a slab-shaped one."""
     L = tuple(0.0025 * n for n in shape)
