@@ -318,3 +318,42 @@ def test_guess_inner_products_from_the_rhs_epilogue(shape, nlig):
     assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-9 * abs(b[0])
     assert a[2] < b[2]
     assert rel_l2(a[3], b[3]) < 1e-10
+
+
+@pytest.mark.parametrize('shape,nlig,env', [((32, 32, 64), 1, {'KSFD_SPEC_FUSE3': '0'}), ((64, 32, 32), 2, {'KSFD_SPEC_FUSE3': '1'}),
+                                           ((64, 128), 2, {'KSFD_SPEC_SPLIT': '1', 'KSFD_SPEC_FUSE': '4'}),
+                                           ((128, 64), 1, {'KSFD_SPEC_SPLIT': '2', 'KSFD_SPEC_FUSE': '4'})])
+def test_unfused_edge_stages_give_the_same_operator(shape, nlig, env):
+    """The fused edge stages of the 3-D y/z kernels (KSFD_SPEC_FUSE3) and of the split column kernel (KSFD_SPEC_FUSE bits 0/1) are a
+    re-ordering of the same transforms: with them switched off (the knobs are read once per process, hence the child) the operator
+    z = M^-1 v agrees with the default build-up to fp32 rounding."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from ksfd_amd import lib as klib
+from ksfd_amd.config import ProblemConfig
+shape, nlig, out = %r, %d, sys.argv[1]
+cfg = ProblemConfig.standard(len(shape), shape, L=tuple(0.003 * n for n in shape), nlig=nlig)
+rng = np.random.default_rng(5)
+rho = 9000 + 90 * rng.standard_normal(cfg.N)
+u = np.concatenate([rho] + [rho * cfg.lig_s[l] / cfg.lig_gamma[l] for l in range(nlig)])
+k = klib.KSFDHip(cfg)
+k.set_state(u)
+k.step(0.0, 0.01, klib.default_step_opts(adapt=0, atol=0.01, rtol=1e-6, pc_type=4))      # frozen planes + means
+v = rng.standard_normal(cfg.F * cfg.N)
+np.save(out, k.spectral_apply(3.0, v))
+k.close()
+''' % (root, shape, nlig)
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, extra in enumerate(({k_: v_ for k_, v_ in env.items() if k_ == 'KSFD_SPEC_SPLIT'}, env)):
+            out = os.path.join(d, 'z%d.npy' % i)
+            r = subprocess.run([sys.executable, '-c', code, out], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=200)
+            assert r.returncode == 0, r.stderr[-1500:]
+            res.append(np.load(out))
+    assert rel_l2(res[1], res[0]) < 2e-6
