@@ -256,16 +256,21 @@ static int op_rhs(ksfd_handle *h, const double *u, int stage, double *out, const
         if (want_norm) return fail(h, KSFD_EINVAL, "op_rhs: fused norm is a 2-D feature");
         KComb C = cmb ? *cmb : KComb{};
         const double *uin = u;
+        const double *Gplane = h->Gb;
         const int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
-        {
+        // first stage of a step: the argument is the resident state itself and G(u) is plane 1 of the frozen coefficients the step has
+        // just made of it (same parameters): nothing to form, no pass
+        const bool reuse_G = C.nin == 0 && u == h->u && h->coef_fresh && h->use_frozen && h->coef && &PP == &h->P;
+        if (reuse_G) Gplane = h->coef + G.plane;
+        else {
             Scope sc(h, KC_GFIELD, 8.0 * ((1 + C.nin) * G.F + (C.nin ? G.F : 0) + 1) * (double)G.plane, C.nin ? vbytes(h, 2 + C.nin) : 0.0);
             NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_gfield_comb<NL>), dim3(nbp), dim3(KSFD_BLOCK), 0, h->st, G, PP, u, C, C.nin ? h->Z : (double *)nullptr, h->Gb));
         }
         if (C.nin) uin = h->Z;
         K3D K = make_k3d(h);
         Scope sc(h, KC_RHS, 8.0 * (2.0 * G.F + 1 + C.nout * G.F) * (double)G.nloc, vbytes(h, 2 + C.nout));
-        if (K.rows == 8) hipLaunchKernelGGL((k_rhs3d_strip<1, 8>), dim3(K.nblocks), dim3(8 * KSFD_WAVE), 0, h->st, G, PP, K, uin, (const double *)h->Gb, S, out, C);
-        else NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs3d_strip<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, uin, (const double *)h->Gb, S, out, C));
+        if (K.rows == 8) hipLaunchKernelGGL((k_rhs3d_strip<1, 8>), dim3(K.nblocks), dim3(8 * KSFD_WAVE), 0, h->st, G, PP, K, uin, Gplane, S, out, C);
+        else NL_DISPATCH(h->P.nlig, if constexpr (NL <= 4) hipLaunchKernelGGL((k_rhs3d_strip<NL>), dim3(K.nblocks), dim3(KSFD_BLOCK), 0, h->st, G, PP, K, uin, Gplane, S, out, C));
     } else {
         int nbp = (int)std::min<long long>((G.plane + KSFD_BLOCK - 1) / KSFD_BLOCK, 4096);
         {
